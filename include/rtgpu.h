@@ -1,0 +1,236 @@
+/*
+ * rtgpu.h -- C ABI of the MI355X render path (librtgpu.so).
+ *
+ * This is the drop-in boundary for the reference's per-pixel render loop:
+ *   raytracer/src/scene.rs:220-246   pub fn Scene::render(&self) -> Vec<Color>
+ * A caller flattens its Scene (scene.rs:35-41) into the plain-data
+ * rt_scene_desc below, uploads it once and asks for the frame.  Everything
+ * here is POD: plain pointers and sizes, little endian, f64 geometry exactly
+ * as the reference holds it, f32 only where the reference is f32.
+ *
+ * Conventions
+ *   - every export returns RT_OK (0) or a negative RT_ERR_* code; no C++
+ *     exception and no HIP error crosses this boundary;
+ *   - the library never keeps a caller pointer past the call that received
+ *     it (rt_scene_upload deep-copies into device memory);
+ *   - output buffers are caller-owned;
+ *   - one rt_ctx is used by one thread at a time; several contexts may exist.
+ */
+#ifndef RTGPU_H
+#define RTGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------ */
+#define RT_OK               0
+#define RT_ERR_INVALID     (-1)  /* malformed description / bad argument          */
+#define RT_ERR_UNSUPPORTED (-2)  /* valid scene the device path does not cover   */
+#define RT_ERR_DEVICE      (-3)  /* HIP runtime failure (no GPU, launch error..) */
+#define RT_ERR_NOMEM       (-4)  /* host or device allocation failed             */
+
+/* ---- closed sets (object/mod.rs:61-70, lighting/mod.rs:36-43,
+ *      skybox.rs:8-11, material.rs:108-117) -------------------------------- */
+enum { RT_OBJ_SPHERE = 0, RT_OBJ_PLANE = 1, RT_OBJ_BOX = 2, RT_OBJ_MESH = 3 };
+enum { RT_TEX_SOLID = 0, RT_TEX_IMAGE = 1, RT_TEX_CHECKER = 2 };
+enum { RT_LIGHT_SUN = 0, RT_LIGHT_POINT = 1, RT_LIGHT_AREA = 2 /* CPU only */ };
+enum { RT_SKY_SOLID = 0, RT_SKY_NORMAL = 1, RT_SKY_CUBEMAP = 2 };
+enum { RT_AREA_SPHERE = 0, RT_AREA_RECTANGLE = 1 };
+
+#define RT_ID_NONE 0xFFFFFFFFu
+
+/* camera.rs:5-27.  chf is the caller's precomputed field (camera.rs:45-47). */
+typedef struct rt_camera {
+    int32_t vw, vh;
+    double  origin[3];
+    double  yaw, pitch, fov, chf;
+} rt_camera;
+
+/* scene.rs:17-32 */
+typedef struct rt_options {
+    uint32_t max_ray_depth;
+    uint8_t  ambient[3];
+    uint8_t  _pad;
+} rt_options;
+
+/* material.rs:108-117.  IMAGE: rgb = w*h*3 bytes, row-major, top-left first
+ * (image::RgbImage after into_rgb8, sdl/src/interpret.rs:1115). */
+typedef struct rt_texture {
+    uint32_t       kind;
+    uint8_t        a[3];      /* SOLID colour / CHECKER colour a */
+    uint8_t        b[3];      /* CHECKER colour b                */
+    uint8_t        _pad[2];
+    uint32_t       w, h;
+    const uint8_t* rgb;
+} rt_texture;
+
+/* material.rs:147-164 */
+typedef struct rt_material {
+    uint32_t texture;         /* index into textures[] */
+    uint32_t _pad;
+    double   reflectiveness, transparency, ior, emissivity;
+} rt_material;
+
+/* object list entry, in scene order (scene.rs:36, scanned in order :61-66) */
+typedef struct rt_object {
+    uint32_t kind;            /* RT_OBJ_*                          */
+    uint32_t material;        /* index into materials[]            */
+    uint32_t payload;         /* index into the array of its kind  */
+    uint32_t _pad;
+} rt_object;
+
+typedef struct rt_sphere { double c[3]; double r; } rt_sphere;            /* sphere.rs:12-21 */
+typedef struct rt_plane  { double p0[3]; double n[3]; float uv_wrap; float _pad; } rt_plane; /* plane.rs:11-25 */
+typedef struct rt_box    { double pos[3]; double half[3]; } rt_box;       /* aabb.rs:13-16 (size = half extent) */
+
+/* acceleration.rs:407-417 TreeNode, flattened in depth-first pre-order
+ * (a before b, the order mesh.rs:326-345 walks it).
+ *   count == 0 : Branch; child a = this index + 1, child b = right_or_first
+ *   count  > 0 : Leaf;   prim_indices[right_or_first .. right_or_first+count)
+ * min/max = the node's `bounding` (centroid is (min+max)*0.5, :76,:116). */
+typedef struct rt_bvh_node {
+    double   min[3], max[3];
+    uint32_t right_or_first;
+    uint32_t count;
+} rt_bvh_node;
+
+/* mesh.rs:91-119.  Index triples are separate for positions, normals and
+ * texture coordinates.  tri_uv may be NULL (no texcoords => uv (0,0)). */
+typedef struct rt_mesh {
+    const double*      verts;      uint32_t n_verts;      uint32_t _p0;   /* [n][3] */
+    const double*      normals;    uint32_t n_normals;    uint32_t _p1;   /* [n][3] */
+    const float*       texcoords;  uint32_t n_texcoords;  uint32_t _p2;   /* [n][2] */
+    const uint32_t*    tri_pos;                                            /* [n_tris][3] */
+    const uint32_t*    tri_nrm;                                            /* [n_tris][3] */
+    const uint32_t*    tri_uv;                                             /* [n_tris][3] or NULL */
+    uint32_t           n_tris;     uint32_t _p3;
+    const rt_bvh_node* nodes;      uint32_t n_nodes;      uint32_t _p4;
+    const uint32_t*    prim_indices; uint32_t n_prims;    uint32_t _p5;
+} rt_mesh;
+
+/* lighting/sun.rs:13-39, point.rs:12-34, area.rs:14-81 */
+typedef struct rt_light {
+    uint32_t kind;
+    uint8_t  color[3];
+    uint8_t  shadows;             /* SUN only */
+    double   intensity;
+    int32_t  specular_power;
+    uint32_t _pad;
+    double   specular_strength;
+    double   v[3];                /* SUN: vector; POINT: position; AREA sphere: centre */
+    double   shadow_coefficient;  /* SUN only */
+    double   max_distance;        /* POINT / AREA */
+    /* AREA only (not supported on the device) */
+    uint32_t area_surface;        /* RT_AREA_* */
+    uint32_t area_iterations;
+    double   area_radius;
+    double   area_corners[4][3];
+} rt_light;
+
+/* skybox.rs:15,25,35-44.  CUBEMAP: 4x3 atlas, cell = w/4 = h/3 (:49-51). */
+typedef struct rt_skybox {
+    uint32_t       kind;
+    uint8_t        color[3];
+    uint8_t        _pad;
+    uint32_t       w, h;
+    const uint8_t* rgb;
+} rt_skybox;
+
+typedef struct rt_scene_desc {
+    rt_camera  camera;
+    rt_options options;
+    const rt_object*   objects;   uint32_t n_objects;   uint32_t _p0;
+    const rt_sphere*   spheres;   uint32_t n_spheres;   uint32_t _p1;
+    const rt_plane*    planes;    uint32_t n_planes;    uint32_t _p2;
+    const rt_box*      boxes;     uint32_t n_boxes;     uint32_t _p3;
+    const rt_mesh*     meshes;    uint32_t n_meshes;    uint32_t _p4;
+    const rt_material* materials; uint32_t n_materials; uint32_t _p5;
+    const rt_texture*  textures;  uint32_t n_textures;  uint32_t _p6;
+    const rt_light*    lights;    uint32_t n_lights;    uint32_t _p7;
+    rt_skybox  skybox;
+} rt_scene_desc;
+
+/* Ray classes.  One ray = one Scene::cast_ray_once call (scene.rs:79):
+ * primary (scene.rs:216), reflection (:169,:190), transmission (:134,:154)
+ * and shadow (sun.rs:89, point.rs:91).  The two same-object helper
+ * intersects of the refraction branch (scene.rs:143-147) are not rays. */
+typedef struct rt_stats {
+    uint64_t rays_primary, rays_reflect, rays_transmit, rays_shadow;
+    uint64_t rays_per_level[8];   /* trace_ray invocations per depth        */
+    double   ms_upload;           /* last rt_scene_upload                   */
+    double   ms_render;           /* kernels of the last frame (HIP events) */
+    double   ms_total;            /* render + copy-out wall time            */
+    double   ms_trace, ms_shade, ms_resolve;   /* per-phase kernel time     */
+    uint64_t device_bytes;        /* device memory held by the context      */
+} rt_stats;
+
+/* result of one probe ray (rt_cast_rays): the fields of object/mod.rs:18-36
+ * plus the ids the reference's Hit lacks */
+typedef struct rt_ray_hit {
+    uint32_t object;              /* scene-order index, RT_ID_NONE on miss */
+    uint32_t prim;                /* triangle index in the mesh's own order, RT_ID_NONE otherwise */
+    double   near_t, far_t;
+    double   normal[3], vnear[3], vfar[3];
+    float    uv[2];
+} rt_ray_hit;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Creates a context on HIP device `device_id`.  Fails with RT_ERR_DEVICE when
+ * no such device exists: there is no CPU fallback behind this library. */
+int rt_ctx_create(int device_id, rt_ctx** out);
+void rt_ctx_destroy(rt_ctx* ctx);
+
+/* Text of the last failure on this context (or of the last failed
+ * rt_ctx_create when ctx is NULL).  Never NULL. */
+const char* rt_last_error(const rt_ctx* ctx);
+
+/* Deep-copies the scene to the device, re-emitting each mesh's top-down BVH
+ * (acceleration.rs:407-448) in the device layout.  May be called again per
+ * frame (sdl/src/main.rs:84-92 sequence mode).  RT_ERR_UNSUPPORTED for area
+ * lights or a BVH deeper than the traversal stack. */
+int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* scene);
+
+/* Replaces Scene::render (scene.rs:220-246).
+ *   rgb_out     vw*vh*3 bytes, row-major, top-left origin (host memory)
+ *   prim_id_out nullable; 2 u32 per pixel = (object index in scene order,
+ *               triangle index in the mesh's own order) of the primary hit;
+ *               RT_ID_NONE = miss / not a mesh
+ *   stats_out   nullable */
+int rt_render(rt_ctx* ctx, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* stats_out);
+
+/* Image-space sharding for one-process-per-GPU runs.  The image is cut into
+ * RT_TILE_W x RT_TILE_H pixel tiles, numbered row-major; shard s of n owns
+ * tiles s, s+n, s+2n, ...  rt_shard_pixels returns the number of pixel slots
+ * (whole tiles, edge tiles padded) shard s produces. */
+#define RT_TILE_W 16
+#define RT_TILE_H 16
+int64_t rt_shard_pixels(int32_t vw, int32_t vh, uint32_t shard, uint32_t n_shards);
+
+/* Renders this shard's tiles into DEVICE memory, compact: slot k*256 + j is
+ * pixel j (row-major inside the tile) of the shard's k-th tile.
+ *   d_rgb   device pointer, rt_shard_pixels()*3 bytes
+ *   d_ids   device pointer or NULL, rt_shard_pixels()*2 u32
+ * The call returns after the kernels have completed. */
+int rt_render_shard(rt_ctx* ctx, uint32_t shard, uint32_t n_shards,
+                    void* d_rgb, void* d_ids, rt_stats* stats_out);
+
+/* Scatters gathered compact shard buffers (shard-major, each padded to
+ * slots_per_shard slots of `elem_bytes` bytes) into a row-major image, both in
+ * DEVICE memory.  elem_bytes is 3 (rgb) or 8 (id pairs). */
+int rt_detile(rt_ctx* ctx, const void* d_gathered, uint32_t n_shards,
+              int64_t slots_per_shard, uint32_t elem_bytes, void* d_image);
+
+/* Probe: casts n arbitrary rays through the uploaded scene with the semantics
+ * of Scene::cast_ray_once (scene.rs:79-82); host pointers.
+ * origins/dirs: n*3 doubles each. */
+int rt_cast_rays(rt_ctx* ctx, uint32_t n, const double* origins, const double* dirs,
+                 rt_ray_hit* hits_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTGPU_H */

@@ -1,0 +1,114 @@
+"""ctypes bindings of liboracle.so, the CPU checker.
+
+TEST INFRASTRUCTURE ONLY (see oracle.cpp): imported by tests/, by
+__graft_entry__.smoke() and by the cpu_baseline leg of bench.py -- never by
+the raytracer_amd package.
+
+PARITY UNPINNED: the reference ships no golden vectors and cannot be built in
+this environment; the checker is pinned by analytic known-answer tests and one
+weak golden image only.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class OrcCounts(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("node_tests", "tri_tests", "sphere_tests", "plane_tests", "box_tests",
+                                           "texel_image", "texel_cubemap", "would_panic")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def _stats_type():
+    from raytracer_amd._native import RtStats
+    return RtStats
+
+
+def _hit_type():
+    from raytracer_amd._native import RtRayHit
+    return RtRayHit
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            raise OSError(f"{path} is missing: build it with `make oracle/liboracle.so`")
+        L = C.CDLL(path)
+        RtStats = _stats_type()
+        vp = C.c_void_p
+        L.rt_cpu_render.argtypes = [vp, C.c_int, vp, vp, C.POINTER(RtStats), C.POINTER(OrcCounts)]
+        L.rt_cpu_render.restype = C.c_int
+        L.rt_cpu_render_pixels.argtypes = [vp, C.c_int, C.c_uint64, vp, vp, vp, C.POINTER(RtStats), C.POINTER(OrcCounts)]
+        L.rt_cpu_render_pixels.restype = C.c_int
+        L.rt_cpu_cast_rays.argtypes = [vp, C.c_uint32, vp, vp, vp]
+        L.rt_cpu_cast_rays.restype = C.c_int
+        for name in ("orc_sphere_intersect", "orc_plane_intersect", "orc_box_intersect"):
+            getattr(L, name).argtypes = [vp, vp, vp, vp]
+            getattr(L, name).restype = C.c_int
+        L.orc_aabb_bool.argtypes = [vp, vp, vp, vp]
+        L.orc_aabb_bool.restype = C.c_int
+        L.orc_triangle_intersect.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.orc_triangle_intersect.restype = C.c_int
+        L.orc_refraction_vec.argtypes = [vp, vp, C.c_double, C.c_double, vp]
+        L.orc_refraction_vec.restype = C.c_int
+        L.orc_color_newf.argtypes = [C.c_double, C.c_double, C.c_double, vp]
+        L.orc_color_newf.restype = None
+        L.orc_camera_direction_at.argtypes = [vp, C.c_double, C.c_double, vp]
+        L.orc_camera_direction_at.restype = None
+        L.orc_camera_chf.argtypes = [C.c_double]
+        L.orc_camera_chf.restype = C.c_double
+        L.orc_texture_at.argtypes = [vp, C.c_float, C.c_float, vp]
+        L.orc_texture_at.restype = None
+        L.orc_skybox_ray_color.argtypes = [vp, vp, vp]
+        L.orc_skybox_ray_color.restype = None
+        L.orc_powi.argtypes = [C.c_double, C.c_int]
+        L.orc_powi.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def render(scene, n_threads=0, pixels=None, ids=True):
+    """Reference-semantics CPU render of a flat scene.
+
+    scene: object with .flatten() -> rt_scene_desc address.
+    pixels: optional uint32 array of linear pixel indices (y*vw + x); the result is then (n, 3).
+    -> rgb, ids, RtStats, OrcCounts
+    """
+    from raytracer_amd.scene import desc_info
+    p = scene.flatten()
+    info = desc_info(p)
+    vw, vh = info["vw"], info["vh"]
+    st, oc = _stats_type()(), OrcCounts()
+    if pixels is None:
+        rgb = np.empty((vh, vw, 3), dtype=np.uint8)
+        idb = np.empty((vh, vw, 2), dtype=np.uint32) if ids else None
+        rc = lib().rt_cpu_render(p, n_threads, rgb.ctypes.data, idb.ctypes.data if ids else None, C.byref(st), C.byref(oc))
+    else:
+        px = np.ascontiguousarray(pixels, dtype=np.uint32)
+        rgb = np.empty((len(px), 3), dtype=np.uint8)
+        idb = np.empty((len(px), 2), dtype=np.uint32) if ids else None
+        rc = lib().rt_cpu_render_pixels(p, n_threads, len(px), px.ctypes.data, rgb.ctypes.data,
+                                        idb.ctypes.data if ids else None, C.byref(st), C.byref(oc))
+    if rc != 0:
+        raise RuntimeError(f"oracle render failed: {rc}")
+    return rgb, idb, st, oc
+
+
+def cast_rays(scene, origins, dirs):
+    o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+    d = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+    hits = (_hit_type() * len(o))()
+    rc = lib().rt_cpu_cast_rays(scene.flatten(), len(o), o.ctypes.data, d.ctypes.data, hits)
+    if rc != 0:
+        raise RuntimeError(f"oracle cast failed: {rc}")
+    return hits

@@ -1,0 +1,477 @@
+// Device functions of the render path: ray/primitive intersection, BVH
+// traversal, texture / skybox sampling and light shading, each following the
+// cited reference lines operation by operation (f64, unfused: this file is
+// compiled with -ffp-contract=off so no multiply-add is contracted).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dev_types.h"
+
+#define DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------- vector.rs
+DEV D3 d3(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEV D3 operator+(D3 a, D3 b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV D3 operator-(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV D3 operator*(D3 a, D3 b) { return d3(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEV D3 operator*(D3 a, double s) { return d3(a.x * s, a.y * s, a.z * s); }
+DEV D3 operator/(D3 a, D3 b) { return d3(a.x / b.x, a.y / b.y, a.z / b.z); }
+DEV D3 operator/(D3 a, double s) { return d3(a.x / s, a.y / s, a.z / s); }
+DEV D3 operator-(D3 a) { return d3(-a.x, -a.y, -a.z); }
+DEV double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                       // vector.rs:60-62
+DEV D3 cross(D3 a, D3 b) { return d3(a.y * b.z - a.z * b.y, -a.x * b.z + a.z * b.x, a.x * b.y - a.y * b.x); }  // :65-71
+DEV double magnitude(D3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }                 // :74-76
+DEV D3 normalize(D3 a) { return a / magnitude(a); }                                            // :79-81
+DEV D3 ld3(const double* p) { return d3(p[0], p[1], p[2]); }
+
+// Rust f64::signum: NaN -> NaN, otherwise +-1 with the sign of x (signum(+-0) = +-1)
+DEV double signum(double x) { return x != x ? x : copysign(1.0, x); }
+// Rust f64::clamp: NaN stays NaN
+DEV double clampd(double x, double lo, double hi) { if (x < lo) x = lo; if (x > hi) x = hi; return x; }
+DEV float clampf(float x, float lo, float hi) { if (x < lo) x = lo; if (x > hi) x = hi; return x; }
+// Rust `as u8` / `as u32`: truncation toward zero, saturating, NaN -> 0
+DEV uint32_t as_u8(double v) { if (!(v > 0.0)) return 0u; if (v >= 255.0) return 255u; return (uint32_t)(int)v; }
+DEV uint32_t as_u32d(double v) { if (!(v > 0.0)) return 0u; if (v >= 4294967295.0) return 4294967295u; return (uint32_t)v; }
+DEV uint32_t as_u32f(float v) { if (!(v > 0.0f)) return 0u; if (v >= 4294967296.0f) return 4294967295u; return (uint32_t)v; }
+DEV float rem_euclid_f(float a, float b) { float r = fmodf(a, b); return r < 0.0f ? r + fabsf(b) : r; }
+// f64::powi with a run-time exponent = compiler-rt __powidf2
+DEV double rt_powi(double a, int b) {
+    const bool recip = b < 0;
+    double r = 1;
+    while (true) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1 / r : r;
+}
+DEV double lerp(double a, double b, double c) { return a + (b - a) * c; }                      // math/mod.rs:17-19
+DEV D3 vlerp(D3 a, D3 b, double t) { return d3(lerp(a.x, b.x, t), lerp(a.y, b.y, t), lerp(a.z, b.z, t)); }
+
+// material.rs:38-44 (Color::newf) packed r | g<<8 | b<<16
+DEV uint32_t newf(double r, double g, double b) {
+    return as_u8(clampd(r, 0., 1.) * 255.0) | (as_u8(clampd(g, 0., 1.) * 255.0) << 8) | (as_u8(clampd(b, 0., 1.) * 255.0) << 16);
+}
+DEV uint32_t to_color(D3 v) { return newf(v.x, v.y, v.z); }
+DEV D3 to_d3(uint32_t c) { return d3((double)(c & 255u) / 255., (double)((c >> 8) & 255u) / 255., (double)((c >> 16) & 255u) / 255.); }  // vector.rs:216-224
+
+// ---------------------------------------------------------------- ray.rs
+struct Ray {
+    D3 o, d, m;          // origin, direction, 1/direction (ray.rs:17-23)
+    uint32_t fx, fy, fz; // sign-bit masks that turn `size` into `s * size`, s = -signum(d)
+};
+DEV Ray ray_new(D3 o, D3 d) {
+    Ray r; r.o = o; r.d = d; r.m = d3(1. / d.x, 1. / d.y, 1. / d.z);
+    // s = -signum(d) is -1 when d's sign bit is clear: flip the sign of size then
+    r.fx = (~(uint32_t)__double2hiint(d.x)) & 0x80000000u;
+    r.fy = (~(uint32_t)__double2hiint(d.y)) & 0x80000000u;
+    r.fz = (~(uint32_t)__double2hiint(d.z)) & 0x80000000u;
+    return r;
+}
+DEV D3 along(const Ray& r, double t) { return r.o + r.d * t; }                                 // ray.rs:26-28
+DEV double flipsign(double v, uint32_t mask) { return __hiloint2double(__double2hiint(v) ^ (int)mask, __double2loint(v)); }
+
+// math/mod.rs:48-63
+DEV bool refraction_vec(D3 dir, D3 normal, double from_ior, double to_ior, D3& out) {
+    double n = from_ior / to_ior;
+    double cos_i = -dot(normal, dir);
+    double sin_t2 = n * n * (1. - cos_i * cos_i);
+    if (sin_t2 > 1.) return false;
+    double cos_t = sqrt(1. - sin_t2);
+    out = dir * n + normal * (n * cos_i - cos_t);
+    return true;
+}
+
+// ---------------------------------------------------------------- object/mod.rs:18-36
+struct Hit { D3 normal; double near; D3 vnear; double far; D3 vfar; float u, v; uint32_t prim; };
+
+// sphere.rs:33-62.  `near_only`: just the hit test and `near`.
+DEV bool sphere_near(const double* s, const Ray& ray, double& near) {
+    D3 origin = ld3(s);
+    double rad2 = s[3] * s[3];
+    D3 l = origin - ray.o;
+    double t2 = dot(l, ray.d);
+    if (t2 < 0.0) return false;
+    double d2 = dot(l, l) - t2 * t2;
+    if (d2 > rad2) return false;
+    double t3 = sqrt(rad2 - d2);
+    near = t2 - t3;
+    return true;
+}
+DEV bool sphere_intersect(const double* s, const Ray& ray, Hit& h) {
+    D3 origin = ld3(s);
+    double rad2 = s[3] * s[3];
+    D3 l = origin - ray.o;
+    double t2 = dot(l, ray.d);
+    if (t2 < 0.0) return false;
+    double d2 = dot(l, l) - t2 * t2;
+    if (d2 > rad2) return false;
+    double t3 = sqrt(rad2 - d2);
+    double t0 = t2 - t3;
+    double t1 = t2 + t3;
+    D3 vtn = along(ray, t0);
+    D3 vtf = along(ray, t1);
+    D3 norm = normalize(vtn - origin);
+    const float PI = 3.14159265358979323846f;
+    h.normal = norm; h.near = t0; h.vnear = vtn; h.far = t1; h.vfar = vtf;
+    h.u = 0.5f + (float)atan2(norm.x, norm.z) / (PI * 2.f);
+    h.v = 0.5f - (float)asin(norm.y) / PI;
+    h.prim = RT_NONE;
+    return true;
+}
+
+// plane.rs:49-79
+DEV bool plane_near(const double* p, const Ray& ray, double& near) {
+    D3 origin = ld3(p), normal = ld3(p + 3);
+    double denom = dot(normal, ray.d);
+    if (fabs(denom) > RT_EPSILON) {
+        double t = dot(origin - ray.o, normal) / denom;
+        if (t > 0.) { near = t; return true; }
+    }
+    return false;
+}
+DEV bool plane_intersect(const double* p, const Ray& ray, Hit& h) {
+    D3 origin = ld3(p), normal = ld3(p + 3);
+    float uv_wrap = (float)p[6];
+    double denom = dot(normal, ray.d);
+    if (fabs(denom) > RT_EPSILON) {
+        double t = dot(origin - ray.o, normal) / denom;
+        if (t > 0.) {
+            D3 pt = along(ray, t);
+            h.normal = normal * -signum(denom);
+            h.near = t; h.vnear = pt; h.far = t; h.vfar = pt;
+            if (normal.y != 0.) {
+                h.u = rem_euclid_f((float)pt.x / uv_wrap, 1.f);
+                h.v = rem_euclid_f((float)pt.z / uv_wrap, 1.f);
+            } else { h.u = 0.f; h.v = 0.f; }
+            h.prim = RT_NONE;
+            return true;
+        }
+    }
+    return false;
+}
+
+// aabb.rs:18-67
+DEV bool box_slabs(D3 pos, D3 size, const Ray& ray, D3& s, D3& t1, double& tn, double& tf) {
+    D3 ro = ray.o - pos;
+    s = d3(-signum(ray.d.x), -signum(ray.d.y), -signum(ray.d.z));
+    t1 = ray.m * (-ro + (s * size));
+    D3 t2 = ray.m * (-ro - (s * size));
+    tn = fmax(fmax(t1.x, t1.y), t1.z);
+    tf = fmin(fmin(t2.x, t2.y), t2.z);
+    return !(tn > tf || tf < 0.);
+}
+DEV bool box_near(const double* b, const Ray& ray, double& near) {
+    D3 s, t1; double tf;
+    return box_slabs(ld3(b), ld3(b + 3), ray, s, t1, near, tf);
+}
+DEV bool box_intersect(D3 pos, D3 size, const Ray& ray, Hit& h) {
+    D3 s, t1; double tn, tf;
+    if (!box_slabs(pos, size, ray, s, t1, tn, tf)) return false;
+    D3 normal;
+    if (t1.x > t1.y && t1.x > t1.z) normal = d3(s.x, 0., 0.);
+    else if (t1.y > t1.z) normal = d3(0., s.y, 0.);
+    else normal = d3(0., 0., s.z);
+    D3 pn = along(ray, tn);
+    D3 pf = along(ray, tf);
+    D3 an = d3(fabs(normal.x), fabs(normal.y), fabs(normal.z));
+    D3 pns = (d3(1., 1., 1.) - an) * (pn - pos) / size;
+    double u0, u1;
+    if (normal.y == 1.) { u0 = pns.x; u1 = pns.z; }
+    else if (normal.y == -1.) { u0 = -pns.x; u1 = -pns.z; }
+    else if (normal.x == 1.) { u0 = -pns.z; u1 = -pns.y; }
+    else if (normal.x == -1.) { u0 = pns.z; u1 = -pns.y; }
+    else if (normal.z == 1.) { u0 = pns.x; u1 = -pns.y; }
+    else if (normal.z == -1.) { u0 = -pns.x; u1 = -pns.y; }
+    else { u0 = 0.; u1 = 0.; }
+    h.normal = normal; h.near = tn; h.vnear = pn; h.far = tf; h.vfar = pf;
+    h.u = (float)u0 * 0.5f + 0.5f;
+    h.v = (float)u1 * 0.5f + 0.5f;
+    h.prim = RT_NONE;
+    return true;
+}
+
+// ---------------------------------------------------------------- mesh BVH
+// acceleration.rs:134-151 on a (centre, half size) box.  s*size is formed by
+// flipping the sign bit (multiplying by +-1 is exact, so the values are those
+// of the reference's `s * size`).
+DEV bool node_box(const double* c, const double* hs, const Ray& ray, double& tn) {
+    double nx = c[0] - ray.o.x, ny = c[1] - ray.o.y, nz = c[2] - ray.o.z;
+    double sx = flipsign(hs[0], ray.fx), sy = flipsign(hs[1], ray.fy), sz = flipsign(hs[2], ray.fz);
+    double t1x = ray.m.x * (nx + sx), t1y = ray.m.y * (ny + sy), t1z = ray.m.z * (nz + sz);
+    double t2x = ray.m.x * (nx - sx), t2y = ray.m.y * (ny - sy), t2z = ray.m.z * (nz - sz);
+    tn = fmax(fmax(t1x, t1y), t1z);
+    double tf = fmin(fmin(t2x, t2y), t2z);
+    return !(tn > tf || tf < 0.);
+}
+
+// mesh.rs:25-59 with the edges precomputed
+DEV bool tri_test(const DTri* T, const Ray& ray, double& t_out, float& u_out, float& v_out) {
+    D3 v0 = ld3(T->v0), edge1 = ld3(T->e1), edge2 = ld3(T->e2);
+    D3 h = cross(ray.d, edge2);
+    double a = dot(edge1, h);
+    if (a > -RT_EPSILON && a < RT_EPSILON) return false;
+    double f = 1. / a;
+    D3 s = ray.o - v0;
+    double u = f * dot(s, h);
+    if (!(u >= 0.0 && u <= 1.0)) return false;
+    D3 q = cross(s, edge1);
+    double v = f * dot(ray.d, q);
+    if (v < 0.0 || u + v > 1.0) return false;
+    double t = f * dot(edge2, q);
+    if (t > RT_EPSILON) { t_out = t; u_out = (float)u; v_out = (float)v; return true; }
+    return false;
+}
+
+struct MeshHit { double t0, t1; uint32_t r0; float u, v; uint32_t n; };   // n = hits kept (0, 1, 2)
+
+enum { TRAV_CLOSEST = 0, TRAV_TWO = 1, TRAV_ANY = 2 };
+
+// The reference gathers every triangle of every leaf whose chain of boxes the
+// ray hits, intersects them all and stable-sorts by t (mesh.rs:326-376).  The
+// walk below visits the nearer child first and skips boxes entered beyond the
+// current answer; it returns the same (t, triangle) because a triangle inside a
+// box cannot be hit before the box is entered, and ties keep the lower
+// leaf-order index, which is the stable sort's order.
+//   TRAV_CLOSEST: nearest hit with t < bound (strict).
+//   TRAV_TWO:     nearest and second nearest (Hit::far, mesh.rs:411-423).
+//   TRAV_ANY:     true as soon as one hit has t <= bound.
+template <int MODE>
+__device__ bool mesh_traverse(const DMesh& M, const Ray& ray, double bound, MeshHit& mh) {
+    mh.n = 0; mh.t0 = bound; mh.t1 = bound; mh.r0 = 0;   // r0 = 0: a hit AT an outside bound never wins the tie
+    double tn_root;
+    if (!node_box(M.root_c, M.root_h, ray, tn_root)) return false;
+
+    uint32_t stack_ref[RT_MAX_STACK];
+    float stack_tn[RT_MAX_STACK];   // entry distance, rounded down: a skip never drops a box that could matter
+    int sp = 0;
+    const uint32_t POP = 0xFFFFFFFFu;
+    uint32_t cur = M.root_ref;
+    while (true) {
+        if (cur & RT_LEAF_BIT) {
+            uint32_t rank = cur & ~RT_LEAF_BIT;
+            while (true) {
+                const DTri* T = &M.tris[rank];
+                const uint32_t last = T->last;
+                double t; float u, v;
+                if (tri_test(T, ray, t, u, v)) {
+                    if (MODE == TRAV_ANY) {
+                        if (t <= bound) return true;
+                    } else if (MODE == TRAV_CLOSEST) {
+                        if (t < mh.t0 || (t == mh.t0 && rank < mh.r0)) { mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v; mh.n = 1; }
+                    } else {
+                        if (mh.n == 0 || t < mh.t0 || (t == mh.t0 && rank < mh.r0)) {
+                            if (mh.n >= 1) { mh.t1 = mh.t0; mh.n = 2; } else mh.n = 1;
+                            mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v;
+                        } else if (mh.n == 1 || t < mh.t1) { mh.t1 = t; mh.n = 2; }
+                    }
+                }
+                if (last) break;
+                ++rank;
+            }
+            cur = POP;
+        } else {
+            const DNode* nd = &M.nodes[cur];
+            double tl, tr;
+            bool hl = node_box(nd->lc, nd->lh, ray, tl);
+            bool hr = node_box(nd->rc, nd->rh, ray, tr);
+            const double limit = (MODE == TRAV_TWO) ? (mh.n == 2 ? mh.t1 : INFINITY) : mh.t0;
+            hl = hl && !(tl > limit);
+            hr = hr && !(tr > limit);
+            const uint32_t lref = nd->lref, rref = nd->rref;
+            if (hl && hr) {
+                // nearer first; equal entry distances keep a before b (the reference's order)
+                const bool left_first = !(tr < tl);
+                stack_ref[sp] = left_first ? rref : lref;
+                stack_tn[sp] = __double2float_rd(left_first ? tr : tl);
+                ++sp;
+                cur = left_first ? lref : rref;
+            } else if (hl) cur = lref;
+            else if (hr) cur = rref;
+            else cur = POP;
+        }
+        if (cur == POP) {
+            const double limit = (MODE == TRAV_TWO) ? (mh.n == 2 ? mh.t1 : INFINITY) : mh.t0;
+            while (sp > 0) {
+                --sp;
+                if (!((double)stack_tn[sp] > limit)) { cur = stack_ref[sp]; break; }
+            }
+            if (cur == POP) break;
+        }
+    }
+    return mh.n > 0;
+}
+
+// mesh.rs:348-439 from a traversal result (nearest triangle, its barycentrics,
+// second-nearest t)
+DEV void mesh_hit_fill(const DMesh& M, const Ray& ray, uint32_t rank, double t0, double t1, float bu, float bv, Hit& h) {
+    uint32_t tri = M.tris[rank].orig;
+    const uint32_t* n = &M.tri_nrm[3 * tri];
+    {   // triangle_intersect_normal, mesh.rs:79-89 (f32 weights, widened)
+        float u = 1.f - bu - bv, v = bu, w = bv;
+        h.normal = ld3(&M.normals[3 * n[0]]) * (double)u + ld3(&M.normals[3 * n[1]]) * (double)v + ld3(&M.normals[3 * n[2]]) * (double)w;
+    }
+    h.near = t0; h.vnear = along(ray, t0);
+    h.far = t1; h.vfar = along(ray, t1);
+    if (M.tri_uv != nullptr && M.n_texcoords != 0) {   // triangle_intersect_uvs, mesh.rs:61-77
+        const uint32_t* c = &M.tri_uv[3 * tri];
+        const float* a = &M.texcoords[2 * c[0]];
+        const float* b = &M.texcoords[2 * c[1]];
+        const float* cc = &M.texcoords[2 * c[2]];
+        float iu = bu, iv = bv, iw = 1.f - bu - bv;
+        float uu = a[0] * iw + b[0] * iu + cc[0] * iv;
+        float vv = a[1] * iw + b[1] * iu + cc[1] * iv;
+        h.u = rem_euclid_f(uu, 1.f);
+        h.v = rem_euclid_f(1.f - vv, 1.f);
+    } else { h.u = 0.f; h.v = 0.f; }
+    h.prim = tri;
+}
+
+// Mesh::intersect as a whole (used for the refraction helper rays, scene.rs:143-147)
+__device__ bool mesh_intersect(const DMesh& M, const Ray& ray, Hit& h) {
+    MeshHit mh;
+    if (!mesh_traverse<TRAV_TWO>(M, ray, INFINITY, mh)) return false;
+    mesh_hit_fill(M, ray, mh.r0, mh.t0, mh.n >= 2 ? mh.t1 : mh.t0, mh.u, mh.v, h);
+    return true;
+}
+
+// ---------------------------------------------------------------- scene casts
+// object.intersect(ray) for object oi (object/mod.rs:61-64)
+__device__ bool object_intersect(const DScene& S, uint32_t oi, const Ray& ray, Hit& h) {
+    const DObject o = S.objects[oi];
+    switch (o.kind) {
+        case 0: return sphere_intersect(&S.spheres[4 * o.payload], ray, h);
+        case 1: return plane_intersect(&S.planes[8 * o.payload], ray, h);
+        case 2: return box_intersect(ld3(&S.boxes[6 * o.payload]), ld3(&S.boxes[6 * o.payload + 3]), ray, h);
+        default: return mesh_intersect(S.meshes[o.payload], ray, h);
+    }
+}
+
+struct Closest { uint32_t obj, rank; double t, t2; float u, v; };
+
+// Scene::cast_ray_once (scene.rs:57-82): every object in scene order; the
+// stable sort by `near` keeps the lowest index among equals, i.e. a later
+// object must be strictly nearer to win.
+__device__ bool cast_closest(const DScene& S, const Ray& ray, Closest& c) {
+    c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
+    bool any = false;
+    const uint32_t n = S.n_objects;
+    for (uint32_t oi = 0; oi < n; oi++) {
+        const DObject o = S.objects[oi];
+        double near; bool hit;
+        if (o.kind == 0) hit = sphere_near(&S.spheres[4 * o.payload], ray, near);
+        else if (o.kind == 1) hit = plane_near(&S.planes[8 * o.payload], ray, near);
+        else if (o.kind == 2) hit = box_near(&S.boxes[6 * o.payload], ray, near);
+        else {
+            MeshHit mh;
+            if (o.need_far) {
+                hit = mesh_traverse<TRAV_TWO>(S.meshes[o.payload], ray, INFINITY, mh);
+                if (hit && (!any || mh.t0 < c.t)) {
+                    c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.n >= 2 ? mh.t1 : mh.t0; c.u = mh.u; c.v = mh.v; any = true;
+                }
+            } else {
+                hit = mesh_traverse<TRAV_CLOSEST>(S.meshes[o.payload], ray, any ? c.t : INFINITY, mh);
+                if (hit) { c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.t0; c.u = mh.u; c.v = mh.v; any = true; }
+            }
+            continue;
+        }
+        if (hit && (!any || near < c.t)) { c.obj = oi; c.rank = RT_NONE; c.t = near; any = true; }
+    }
+    return any;
+}
+
+// Shadow casts.  sun.rs:89: any object the ray hits at all; point.rs:91-92:
+// the nearest hit has near <= dist, i.e. some object has near <= dist.
+__device__ bool cast_any(const DScene& S, const Ray& ray, bool limited, double dist) {
+    const uint32_t n = S.n_objects;
+    for (uint32_t oi = 0; oi < n; oi++) {
+        const DObject o = S.objects[oi];
+        double near; bool hit;
+        if (o.kind == 0) hit = sphere_near(&S.spheres[4 * o.payload], ray, near);
+        else if (o.kind == 1) hit = plane_near(&S.planes[8 * o.payload], ray, near);
+        else if (o.kind == 2) hit = box_near(&S.boxes[6 * o.payload], ray, near);
+        else {
+            MeshHit mh;
+            if (mesh_traverse<TRAV_ANY>(S.meshes[o.payload], ray, limited ? dist : INFINITY, mh)) return true;
+            continue;
+        }
+        if (hit && (!limited || near <= dist)) return true;
+    }
+    return false;
+}
+
+// Rebuilds the full Hit of the closest object from the trace record
+__device__ void closest_hit_fill(const DScene& S, const Ray& ray, uint32_t obj, uint32_t rank, double t, double t2, float u, float v, Hit& h) {
+    const DObject o = S.objects[obj];
+    if (o.kind == 3) mesh_hit_fill(S.meshes[o.payload], ray, rank, t, t2, u, v, h);
+    else object_intersect(S, obj, ray, h);
+}
+
+// ---------------------------------------------------------------- material.rs:119-141
+DEV uint32_t ldrgb(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+DEV uint32_t texture_at(const DMaterial& m, float u, float v) {
+    if (m.tex_kind == 0) return m.a_rgb;
+    if (m.tex_kind == 1) {
+        float w = (float)m.tex_w, h = (float)m.tex_h;
+        uint32_t x = as_u32f(clampf(u * w, 0.f, w - 1.f));
+        uint32_t y = as_u32f(clampf(v * h, 0.f, h - 1.f));
+        return ldrgb(&m.tex_rgb[3 * ((size_t)y * m.tex_w + x)]);
+    }
+    bool a = u > 0.5f, b = v > 0.5f;
+    return a == b ? m.a_rgb : m.b_rgb;
+}
+
+// ---------------------------------------------------------------- skybox.rs
+DEV uint32_t sky_px(const DScene& S, double xx, double yy) {
+    uint32_t xi = as_u32d(xx), yi = as_u32d(yy);
+    if (xi >= S.sky_w || yi >= S.sky_h) return 0u;   // the reference's get_pixel would panic
+    return ldrgb(&S.sky_pix[3 * ((size_t)yi * S.sky_w + xi)]);
+}
+__device__ uint32_t skybox_color(const DScene& S, D3 dir) {
+    if (S.sky_kind == 0) return S.sky_rgb;                                                       // skybox.rs:17-21
+    if (S.sky_kind == 1) return newf(dir.x / 2. + 0.5, dir.y / 2. + 0.5, dir.z / 2. + 0.5);      // :27-31, material.rs:47-49
+    // skybox.rs:89-119
+    Ray r = ray_new(dir * 2., -dir);
+    Hit h;
+    if (!box_intersect(d3(0., 0., 0.), d3(0.5, 0.5, 0.5), r, h)) return 0u;
+    D3 normal = h.normal;
+    uint32_t cx, cy;
+    if (normal.z == -1.) { cx = 1; cy = 1; }
+    else if (normal.x == -1.) { cx = 2; cy = 1; }
+    else if (normal.x == 1.) { cx = 0; cy = 1; }
+    else if (normal.z == 1.) { cx = 3; cy = 1; }
+    else if (normal.y == 1.) { cx = 1; cy = 0; }
+    else if (normal.y == -1.) { cx = 1; cy = 2; }
+    else return 0u;
+    float u = h.u, v = h.v;
+    if (normal.y == 1.) { u = 1.f - h.u; v = 1.f - h.v; }
+    else if (normal.y == -1.) { u = h.u; v = 1.f - h.v; }
+    // poll_tex, skybox.rs:64-86
+    uint32_t cell = S.sky_w / 4;
+    double x = (double)(cx * cell) + (double)u * (double)(cell - 1);
+    double y = (double)(cy * cell) + (double)v * (double)(cell - 1);
+    if (fmod(x, 1.) == 0. && fmod(y, 1.) == 0.) return sky_px(S, x, y);
+    double xmin = floor(x), xmax = ceil(x), ymin = floor(y), ymax = ceil(y);
+    D3 c00 = to_d3(sky_px(S, xmin, ymin)), c10 = to_d3(sky_px(S, xmax, ymin));
+    D3 c01 = to_d3(sky_px(S, xmin, ymax)), c11 = to_d3(sky_px(S, xmax, ymax));
+    double tx = (x - xmin) / (xmax - xmin), ty = (y - ymin) / (ymax - ymin);
+    D3 a = c00 * (1. - tx) + c10 * tx;                                                           // blerp, math/mod.rs:22-26
+    D3 b = c01 * (1. - tx) + c11 * tx;
+    return to_color(a * (1. - ty) + b * ty);
+}
+
+// ---------------------------------------------------------------- camera.rs:55-67
+DEV D3 camera_direction(const DScene& S, double x, double y) {
+    double nx = x - S.half_w;
+    double ny = y - S.half_h;
+    D3 f = normalize(d3(nx, -ny, -S.cam_z));
+    // row 2 of from_forward(f) * rot (matrix.rs:38-57,148-185): the products are
+    // accumulated from 0.0 in k order; forward() negates it (matrix.rs:113-115)
+    double a0 = -f.x, a1 = -f.y, a2 = -f.z;
+    double o0 = 0., o1 = 0., o2 = 0.;
+    o0 += a0 * S.rot[0][0]; o0 += a1 * S.rot[1][0]; o0 += a2 * S.rot[2][0]; o0 += 0. * 0.;
+    o1 += a0 * S.rot[0][1]; o1 += a1 * S.rot[1][1]; o1 += a2 * S.rot[2][1]; o1 += 0. * 0.;
+    o2 += a0 * S.rot[0][2]; o2 += a1 * S.rot[1][2]; o2 += a2 * S.rot[2][2]; o2 += 0. * 0.;
+    return d3(-o0, -o1, -o2);
+}

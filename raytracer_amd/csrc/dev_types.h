@@ -1,0 +1,108 @@
+// Device-side data layout of an uploaded scene (gfx950).  All geometry stays
+// f64 -- the reference path is f64 end to end (raytracer/src/math/vector.rs:20-24)
+// and its 1e-11 ray offsets (scene.rs:13) vanish in f32.
+#pragma once
+#include <stdint.h>
+
+#define RT_EPSILON 0.00000000001   /* scene.rs:13 */
+#define RT_METER 2.                /* lighting/mod.rs:13 */
+#define RT_NONE 0xFFFFFFFFu
+#define RT_MAX_STACK 64            /* deepest mesh BVH the traversal stack holds */
+
+struct D3 { double x, y, z; };
+
+// One inner node of a mesh's top-down BVH (acceleration.rs:407-417), re-emitted
+// so that a single 128-byte fetch carries BOTH children's boxes: a visit tests
+// the two boxes it needs next without touching the children themselves.
+// Boxes are stored as centre + half size, the two quantities the reference's
+// slab test derives from min/max on every call (acceleration.rs:76,135).
+#define RT_LEAF_BIT 0x80000000u
+struct __attribute__((aligned(16))) DNode {
+    double lc[3], lh[3];   // child a: centre, half size
+    double rc[3], rh[3];   // child b
+    uint32_t lref, rref;   // inner child: node index; leaf child: RT_LEAF_BIT | first triangle (leaf order)
+    uint32_t pad[6];
+};
+
+// One triangle in leaf order (the order mesh.rs:326-345 gathers candidates):
+// v0 and the two edges triangle_intersect forms first (mesh.rs:26-27), the
+// triangle's index in the mesh's own order, and whether it ends its leaf.
+struct __attribute__((aligned(16))) DTri { double v0[3], e1[3], e2[3]; uint32_t orig, last; };
+
+struct DMesh {
+    const DNode* nodes;        // inner nodes; nodes[0] is the root when n_inner > 0
+    const DTri* tris;          // leaf order
+    const double* normals;     // [n][3]
+    const float* texcoords;    // [n][2]
+    const uint32_t* tri_nrm;   // [n_tris][3], mesh order
+    const uint32_t* tri_uv;    // [n_tris][3] or null
+    double root_c[3], root_h[3];
+    uint32_t n_inner, n_tris, n_texcoords;
+    uint32_t root_ref;         // 0 (inner node 0), or RT_LEAF_BIT | 0 when the root itself is a leaf
+};
+
+struct DObject {
+    uint32_t kind, material, payload;
+    uint32_t need_far;         // mesh only: material needs Hit::far (transparency with ior == 1)
+};
+
+struct DMaterial {
+    uint32_t tex_kind;
+    uint32_t tex_w, tex_h;
+    uint32_t a_rgb, b_rgb;     // packed r | g<<8 | b<<16
+    uint32_t _pad;
+    const uint8_t* tex_rgb;
+    double reflectiveness, transparency, ior, emissivity;
+};
+
+struct DLight {
+    uint32_t kind;
+    int32_t specular_power;
+    uint32_t shadows, _pad;
+    double col[3];             // colour / 255 (vector.rs:216-224)
+    double intensity, specular_strength;
+    double v[3];               // sun: vector; point: position
+    double shadow_coefficient, max_distance;
+};
+
+struct DScene {
+    // camera (camera.rs:55-67): rot = from_euler_xyz(-pitch, yaw, 0) hoisted to the host
+    double cam_o[3];
+    double rot[3][3];
+    double half_w, half_h, cam_z;   // vw*0.5, vh*0.5, vh*0.5*chf
+    int32_t vw, vh;
+    uint32_t max_depth;
+    uint32_t n_objects, n_lights, n_meshes;
+    double ambient[3];              // ambient / 255
+    const DObject* objects;
+    const double* spheres;          // [n][4] c, r
+    const double* planes;           // [n][8] p0, n, uv_wrap (as double holding the f32 value), pad
+    const double* boxes;            // [n][6] pos, half
+    const DMesh* meshes;
+    const DMaterial* materials;
+    const DLight* lights;
+    uint32_t sky_kind, sky_rgb;     // packed solid colour
+    uint32_t sky_w, sky_h;
+    const uint8_t* sky_pix;
+};
+
+// Structure-of-arrays state of one wavefront level: every ray of one
+// trace_ray depth (scene.rs:85) across the frame.
+struct DLevel {
+    double* ro[3]; double* rd[3];                 // the ray
+    uint32_t* hit_obj; uint32_t* hit_prim;        // closest hit: object, triangle (leaf order)
+    double* hit_t; double* hit_t2;                // mesh hits: near / far t
+    float* hit_u; float* hit_v;                   // mesh hits: barycentrics (f32, mesh.rs:53-54)
+    double* lit[3];                               // lit colour before the child mixes (scene.rs:122)
+    double* w_t; double* w_r; double* emis;       // mix weights
+    uint32_t* child0; uint32_t* child1;           // index in the next level (transmission, reflection)
+    uint32_t* base_flags;                         // base colour rgb | flags << 24
+    uint32_t* result;                             // final colour of this trace_ray call, packed rgb
+};
+
+enum { NF_DONE = 1, NF_TRANSPARENT = 2, NF_T_REFLECT = 4, NF_REFLECT = 8, NF_EMISSIVE = 16 };
+
+struct DCounters {
+    unsigned long long rays_primary, rays_reflect, rays_transmit, rays_shadow;
+    unsigned long long next_count;   // rays appended to the next level
+};

@@ -1,0 +1,323 @@
+// Wavefront kernels of the render path.
+//
+// The reference runs trace_ray recursively per pixel (scene.rs:85-206) and
+// quantises every call's result to 8 bits before the caller mixes it in.  Here
+// each recursion depth is one "level": a flat array of rays.  Per level,
+//   k_trace   finds every ray's closest hit            (scene.rs:97, cast_ray_once)
+//   k_shade   rebuilds the Hit, samples the texture, runs the lights with their
+//             shadow rays, and appends the child rays to the next level
+//                                                      (scene.rs:102-196)
+// and, once the deepest level is done, levels are folded back bottom-up by
+//   k_resolve which applies the lerps of scene.rs:176-202 to the children's
+//             already-quantised colours and truncates to 8 bits itself.
+#pragma once
+#include "dev_rt.h"
+
+#define RT_BLOCK 256
+#define RT_INACTIVE 0xFFFFFFFEu   // padding slot of an edge tile
+
+struct ShardMap {
+    uint32_t shard, n_shards, tiles_x, n_tiles;   // image tiles: 16 x 16 pixels, row-major
+    uint32_t row_major_out;                       // 1: write the frame row-major; 0: compact slot order
+};
+
+DEV bool slot_pixel(const ShardMap& m, int32_t vw, int32_t vh, uint32_t slot, int32_t& x, int32_t& y) {
+    uint32_t k = slot >> 8, j = slot & 255u;
+    uint64_t gid = (uint64_t)k * m.n_shards + m.shard;
+    if (gid >= m.n_tiles) return false;
+    uint32_t tx = (uint32_t)(gid % m.tiles_x), ty = (uint32_t)(gid / m.tiles_x);
+    x = (int32_t)(tx * 16u + (j & 15u));
+    y = (int32_t)(ty * 16u + (j >> 4));
+    return x < vw && y < vh;
+}
+
+DEV Ray load_ray(const DLevel& L, uint32_t i) {
+    return ray_new(d3(L.ro[0][i], L.ro[1][i], L.ro[2][i]), d3(L.rd[0][i], L.rd[1][i], L.rd[2][i]));
+}
+DEV void store_ray(const DLevel& L, uint32_t i, D3 o, D3 d) {
+    L.ro[0][i] = o.x; L.ro[1][i] = o.y; L.ro[2][i] = o.z;
+    L.rd[0][i] = d.x; L.rd[1][i] = d.y; L.rd[2][i] = d.z;
+}
+
+// Level 0 only: primary rays (scene.rs:210-217, camera.rs:55-59)
+__global__ __launch_bounds__(RT_BLOCK) void k_primary(const DScene* Sp, DLevel L, uint32_t n, ShardMap map) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const DScene& S = *Sp;
+    int32_t x, y;
+    if (!slot_pixel(map, S.vw, S.vh, i, x, y)) {
+        L.hit_obj[i] = RT_INACTIVE;
+        store_ray(L, i, d3(0., 0., 0.), d3(0., 0., 1.));
+        return;
+    }
+    L.hit_obj[i] = RT_NONE;
+    store_ray(L, i, ld3(S.cam_o), camera_direction(S, (double)x, (double)y));
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, uint32_t n) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (L.hit_obj[i] == RT_INACTIVE) return;
+    const DScene& S = *Sp;
+    Ray ray = load_ray(L, i);
+    Closest c;
+    cast_closest(S, ray, c);
+    L.hit_obj[i] = c.obj; L.hit_prim[i] = c.rank;
+    L.hit_t[i] = c.t; L.hit_t2[i] = c.t2; L.hit_u[i] = c.u; L.hit_v[i] = c.v;
+}
+
+DEV uint32_t lane_id() { return __lane_id(); }
+DEV unsigned long long lanes_below() { return (1ull << lane_id()) - 1ull; }
+
+// Appends one slot per flagged lane of the wave to the next level; one atomic per wave.
+DEV uint32_t wave_append(bool want, unsigned long long* counter) {
+    unsigned long long mask = __ballot(want);
+    uint32_t total = (uint32_t)__popcll(mask);
+    uint32_t base = 0;
+    if (total) {
+        int leader = __ffsll((long long)mask) - 1;
+        if ((int)lane_id() == leader) base = (uint32_t)atomicAdd(counter, (unsigned long long)total);
+        base = __shfl(base, leader);
+    }
+    return base + (uint32_t)__popcll(mask & lanes_below());
+}
+DEV void wave_count(uint32_t v, unsigned long long* counter) {
+    // sum v over the wave, one atomic
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane_id() == 0 && v) atomicAdd(counter, (unsigned long long)v);
+}
+
+// One light's contribution (lighting/sun.rs:72-97, point.rs:66-105); returns
+// false when the light contributes LightShading::default() (point.rs:72-74).
+__device__ bool light_shading(const DScene& S, const DLight& Lt, const Ray& ray, const Hit& hit,
+                              double& diffuse, double& specular, double& intensity, uint32_t& n_shadow) {
+    const double FMAX = 1.7976931348623157e308;
+    if (Lt.kind == 0) {
+        D3 lvec = -ld3(Lt.v);
+        diffuse = clampd(dot(hit.normal, lvec), 0., FMAX);
+        D3 halfway = normalize(lvec - ray.d);
+        specular = rt_powi(clampd(dot(hit.normal, halfway), 0., FMAX), Lt.specular_power);
+        if (Lt.shadows) {
+            Ray sr = ray_new(hit.vnear + hit.normal * RT_EPSILON, lvec);
+            n_shadow++;
+            if (cast_any(S, sr, false, 0.)) { diffuse *= Lt.shadow_coefficient; specular *= Lt.shadow_coefficient; }
+        }
+        intensity = Lt.intensity;
+        return true;
+    }
+    D3 lvec = ld3(Lt.v) - hit.vnear;
+    double dist = magnitude(lvec);
+    if (dist > Lt.max_distance) return false;
+    lvec = lvec / dist;
+    diffuse = clampd(dot(hit.normal, lvec), 0., FMAX);
+    D3 halfway = normalize(lvec - ray.d);
+    specular = rt_powi(clampd(dot(hit.normal, halfway), 0., FMAX), Lt.specular_power);
+    Ray sr = ray_new(hit.vnear + hit.normal * RT_EPSILON, lvec);
+    n_shadow++;
+    if (cast_any(S, sr, true, dist)) { diffuse *= 0.; specular *= 0.; }
+    double q = dist / RT_METER;
+    intensity = Lt.intensity / (q * q);
+    return true;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, DLevel N, uint32_t n, uint32_t depth,
+                                                    uint32_t next_cap, DCounters* C, uint32_t* ids_out, ShardMap map) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const DScene& S = *Sp;
+    bool active = i < n;
+    uint32_t obj = active ? L.hit_obj[i] : RT_INACTIVE;
+    if (active && obj == RT_INACTIVE) {
+        L.result[i] = 0u; L.base_flags[i] = (uint32_t)NF_DONE << 24;
+        if (ids_out && depth == 0) { ids_out[2 * (size_t)i] = RT_NONE; ids_out[2 * (size_t)i + 1] = RT_NONE; }
+        active = false;
+    }
+    uint32_t n_shadow = 0;
+    bool want0 = false, want1 = false;
+    D3 c0o = d3(0, 0, 0), c0d = d3(0, 0, 1), c1o = d3(0, 0, 0), c1d = d3(0, 0, 1);
+
+    if (active) {
+        Ray ray = load_ray(L, i);
+        if (obj == RT_NONE) {                                        // scene.rs:99
+            L.result[i] = skybox_color(S, ray.d);
+            L.base_flags[i] = (uint32_t)NF_DONE << 24;
+            if (ids_out && depth == 0) { ids_out[2 * (size_t)i] = RT_NONE; ids_out[2 * (size_t)i + 1] = RT_NONE; }
+        } else {
+            Hit hit;
+            closest_hit_fill(S, ray, obj, L.hit_prim[i], L.hit_t[i], L.hit_t2[i], L.hit_u[i], L.hit_v[i], hit);
+            if (ids_out && depth == 0) { ids_out[2 * (size_t)i] = obj; ids_out[2 * (size_t)i + 1] = hit.prim; }
+            const DMaterial& mat = S.materials[S.objects[obj].material];
+            const uint32_t base_rgb = texture_at(mat, hit.u, hit.v);       // scene.rs:102
+            D3 color = to_d3(base_rgb);
+            if (mat.emissivity == 1.) {                                    // scene.rs:105-107
+                L.result[i] = to_color(color);
+                L.base_flags[i] = (uint32_t)NF_DONE << 24;
+            } else {
+                D3 sum = ld3(S.ambient);                                   // scene.rs:110-120
+                for (uint32_t li = 0; li < S.n_lights; li++) {
+                    const DLight& Lt = S.lights[li];
+                    double diff = 0., spec = 0., inten = 0.;
+                    light_shading(S, Lt, ray, hit, diff, spec, inten, n_shadow);
+                    D3 lcol = ld3(Lt.col);
+                    D3 dv = lcol * diff;
+                    D3 sv = lcol * (spec * Lt.specular_strength);
+                    sum = sum + (dv + sv) * inten;
+                }
+                color = color * sum;                                       // scene.rs:122
+                uint32_t flags = 0;
+                double w_r = 0.;
+                const double refl = mat.reflectiveness, transp = mat.transparency, ior = mat.ior;
+                if (transp > RT_EPSILON && depth < S.max_depth) {          // scene.rs:129-180
+                    flags |= NF_TRANSPARENT;
+                    if (ior == 1.) {
+                        want0 = true; c0o = hit.vfar; c0d = ray.d;         // :134
+                    } else {
+                        D3 ref_vec;
+                        if (refraction_vec(ray.d, hit.normal, 1., ior, ref_vec)) {           // :140 (the reference unwraps)
+                            Hit ref_hit;
+                            if (object_intersect(S, obj, ray_new(hit.vnear - ref_vec, ref_vec), ref_hit)) {              // :143
+                                Hit exit_hit;
+                                if (object_intersect(S, obj, ray_new(ref_hit.vfar + ref_vec, -ref_vec), exit_hit)) {     // :145-146
+                                    D3 exit_ref_vec;
+                                    if (refraction_vec(ref_vec, -exit_hit.normal, ior, 1., exit_ref_vec)) {              // :148-153
+                                        want0 = true; c0o = ref_hit.vfar + exit_ref_vec * RT_EPSILON; c0d = exit_ref_vec;  // :155
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (refl > RT_EPSILON) {                               // :165-177
+                        double dd = dot(-ray.d, hit.normal);
+                        dd = dd * dd;
+                        flags |= NF_T_REFLECT;
+                        w_r = 1. - dd;
+                        want1 = true;
+                    }
+                }
+                if (refl > RT_EPSILON && depth < S.max_depth && transp < RT_EPSILON) {   // scene.rs:182-196
+                    flags |= NF_REFLECT;
+                    w_r = refl;
+                    want1 = true;
+                }
+                if (want1) {                                               // ray.reflect, ray.rs:43-46
+                    c1o = hit.vnear + hit.normal * RT_EPSILON;
+                    c1d = ray.d - hit.normal * (2. * dot(ray.d, hit.normal));
+                }
+                if (mat.emissivity > 0.) flags |= NF_EMISSIVE;             // scene.rs:200-205
+                if (!want0 && !want1) {
+                    // no child calls: the result is final now
+                    if (flags & NF_TRANSPARENT) color = vlerp(color, color, transp);     // :179 with transparency_color == color
+                    if (flags & NF_EMISSIVE) color = vlerp(color, to_d3(base_rgb), mat.emissivity);
+                    L.result[i] = to_color(color);
+                    L.base_flags[i] = (uint32_t)NF_DONE << 24;
+                } else {
+                    L.lit[0][i] = color.x; L.lit[1][i] = color.y; L.lit[2][i] = color.z;
+                    L.w_t[i] = transp; L.w_r[i] = w_r; L.emis[i] = mat.emissivity;
+                    L.base_flags[i] = (base_rgb & 0xFFFFFFu) | (flags << 24);
+                }
+            }
+        }
+    }
+    // append the children to the next level (whole wave takes part)
+    uint32_t s0 = wave_append(want0, &C->next_count);
+    uint32_t s1 = wave_append(want1, &C->next_count);
+    if (want0 && s0 >= next_cap) want0 = false;
+    if (want1 && s1 >= next_cap) want1 = false;
+    if (active && !((L.base_flags[i] >> 24) & NF_DONE)) {
+        L.child0[i] = want0 ? s0 : RT_NONE;
+        L.child1[i] = want1 ? s1 : RT_NONE;
+    }
+    if (want0) { store_ray(N, s0, c0o, c0d); N.hit_obj[s0] = RT_NONE; }
+    if (want1) { store_ray(N, s1, c1o, c1d); N.hit_obj[s1] = RT_NONE; }
+    wave_count(n_shadow, &C->rays_shadow);
+    wave_count(want0 ? 1u : 0u, &C->rays_transmit);
+    wave_count(want1 ? 1u : 0u, &C->rays_reflect);
+}
+
+// Folds one level into its parents' view: scene.rs:176-205 on the children's
+// 8-bit results.  Level 0 also writes the frame.
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(const DScene* Sp, DLevel L, DLevel N, uint32_t n, int level0,
+                                                      uint8_t* rgb_out, ShardMap map) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t bf = L.base_flags[i];
+    const uint32_t flags = bf >> 24;
+    uint32_t res;
+    if (flags & NF_DONE) res = L.result[i];
+    else {
+        D3 color = d3(L.lit[0][i], L.lit[1][i], L.lit[2][i]);
+        const double w_r = L.w_r[i];
+        const uint32_t c0 = L.child0[i], c1 = L.child1[i];
+        if (flags & NF_TRANSPARENT) {
+            D3 tc = color;
+            if (c0 != RT_NONE) tc = to_d3(N.result[c0]);                                       // :136,:158
+            if ((flags & NF_T_REFLECT) && c1 != RT_NONE) tc = vlerp(tc, to_d3(N.result[c1]), w_r);   // :176
+            color = vlerp(color, tc, L.w_t[i]);                                                // :179
+        }
+        if ((flags & NF_REFLECT) && c1 != RT_NONE) color = vlerp(color, to_d3(N.result[c1]), w_r);   // :195
+        if (flags & NF_EMISSIVE) color = vlerp(color, to_d3(bf & 0xFFFFFFu), L.emis[i]);       // :202
+        res = to_color(color);
+        L.result[i] = res;
+    }
+    if (level0) {
+        size_t o = i;
+        if (map.row_major_out) {
+            const DScene& S = *Sp;
+            int32_t x, y;
+            if (!slot_pixel(map, S.vw, S.vh, i, x, y)) return;
+            o = (size_t)y * (size_t)S.vw + (size_t)x;
+        }
+        rgb_out[3 * o] = (uint8_t)(res & 255u); rgb_out[3 * o + 1] = (uint8_t)((res >> 8) & 255u); rgb_out[3 * o + 2] = (uint8_t)((res >> 16) & 255u);
+    }
+}
+
+// ids (2 x u32 per slot) compact -> row-major, for rt_render
+__global__ __launch_bounds__(RT_BLOCK) void k_ids_rowmajor(const DScene* Sp, const uint32_t* compact, uint32_t* out, uint32_t n, ShardMap map) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const DScene& S = *Sp;
+    int32_t x, y;
+    if (!slot_pixel(map, S.vw, S.vh, i, x, y)) return;
+    size_t o = (size_t)y * (size_t)S.vw + (size_t)x;
+    out[2 * o] = compact[2 * (size_t)i]; out[2 * o + 1] = compact[2 * (size_t)i + 1];
+}
+
+// Gathered compact shard buffers -> row-major image (rt_detile)
+__global__ __launch_bounds__(RT_BLOCK) void k_detile(const uint8_t* gathered, uint8_t* image, int32_t vw, int32_t vh, uint32_t n_shards,
+                                                     unsigned long long slots_per_shard, uint32_t elem_bytes, uint32_t tiles_x, uint32_t n_tiles) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+    const unsigned long long total = slots_per_shard * n_shards;
+    if (g >= total) return;
+    ShardMap m; m.shard = (uint32_t)(g / slots_per_shard); m.n_shards = n_shards; m.tiles_x = tiles_x; m.n_tiles = n_tiles; m.row_major_out = 1;
+    int32_t x, y;
+    if (!slot_pixel(m, vw, vh, (uint32_t)(g % slots_per_shard), x, y)) return;
+    const uint8_t* src = gathered + g * elem_bytes;
+    uint8_t* dst = image + ((size_t)y * (size_t)vw + (size_t)x) * elem_bytes;
+    for (uint32_t b = 0; b < elem_bytes; b++) dst[b] = src[b];
+}
+
+// Probe rays (rt_cast_rays): Scene::cast_ray_once with the full Hit
+struct DProbeHit { uint32_t object, prim; double near_t, far_t; double normal[3], vnear[3], vfar[3]; float uv[2]; };
+__global__ __launch_bounds__(RT_BLOCK) void k_probe(const DScene* Sp, const double* origins, const double* dirs, DProbeHit* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const DScene& S = *Sp;
+    Ray ray = ray_new(ld3(origins + 3 * (size_t)i), ld3(dirs + 3 * (size_t)i));
+    DProbeHit o;
+    o.object = RT_NONE; o.prim = RT_NONE; o.near_t = 0.; o.far_t = 0.;
+    for (int k = 0; k < 3; k++) { o.normal[k] = 0.; o.vnear[k] = 0.; o.vfar[k] = 0.; }
+    o.uv[0] = 0.f; o.uv[1] = 0.f;
+    // a probe reports Hit::far for every object kind, so meshes are walked in two-nearest mode
+    bool any = false; uint32_t best = RT_NONE; Hit bh;
+    for (uint32_t oi = 0; oi < S.n_objects; oi++) {
+        Hit h;
+        if (object_intersect(S, oi, ray, h) && (!any || h.near < bh.near)) { any = true; best = oi; bh = h; }
+    }
+    if (any) {
+        o.object = best; o.prim = bh.prim; o.near_t = bh.near; o.far_t = bh.far;
+        o.normal[0] = bh.normal.x; o.normal[1] = bh.normal.y; o.normal[2] = bh.normal.z;
+        o.vnear[0] = bh.vnear.x; o.vnear[1] = bh.vnear.y; o.vnear[2] = bh.vnear.z;
+        o.vfar[0] = bh.vfar.x; o.vfar[1] = bh.vfar.y; o.vfar[2] = bh.vfar.z;
+        o.uv[0] = bh.u; o.uv[1] = bh.v;
+    }
+    out[i] = o;
+}

@@ -1,0 +1,589 @@
+// librtgpu.so: the C ABI of include/rtgpu.h on HIP for gfx950.
+//
+// Host side of the render path: scene upload (deep copy + re-emission of each
+// mesh BVH in the device layout), the per-frame wavefront loop over trace_ray
+// depths, and the copy-out.  There is no CPU rendering path in this library: a
+// missing device is an error.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rtgpu.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct LevelAlloc { void* base = nullptr; size_t cap = 0; DLevel lv; };
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void*> scene_allocs;
+    DScene hscene;                 // host copy of the device scene header
+    DScene* dscene = nullptr;
+    bool have_scene = false;
+    int32_t vw = 0, vh = 0;
+    uint32_t max_depth = 0;
+    std::vector<LevelAlloc> levels;
+    DCounters* dcounters = nullptr;
+    DCounters* hcounters = nullptr;   // pinned
+    void* d_out = nullptr; size_t d_out_cap = 0;      // rgb staging for rt_render
+    void* d_ids = nullptr; size_t d_ids_cap = 0;      // compact ids
+    void* d_ids2 = nullptr; size_t d_ids2_cap = 0;    // row-major ids
+    hipEvent_t ev[8];
+    size_t scene_bytes = 0, work_bytes = 0;
+    double ms_upload = 0.;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+            return RT_ERR_DEVICE;                                                                   \
+        }                                                                                           \
+    } while (0)
+
+int fail(rt_ctx* c, int code, const std::string& msg) { c->err = msg; return code; }
+
+void free_scene(rt_ctx* c) {
+    for (void* p : c->scene_allocs) (void)hipFree(p);
+    c->scene_allocs.clear();
+    c->scene_bytes = 0;
+    c->have_scene = false;
+}
+
+template <typename T>
+int upload(rt_ctx* c, const T* src, size_t n, const T** out) {
+    *out = nullptr;
+    if (n == 0) return RT_OK;
+    void* d = nullptr;
+    if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipMalloc failed during scene upload");
+    c->scene_allocs.push_back(d);
+    c->scene_bytes += n * sizeof(T);
+    HIP_TRY(c, hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(d);
+    return RT_OK;
+}
+
+uint32_t pack_rgb(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+
+// matrix.rs:148-185 (4x4 product accumulated from 0.0 in k order) for the
+// camera rotation the reference rebuilds per pixel (camera.rs:56-57)
+struct M4 { double a[4][4]; };
+M4 m4mul(const M4& A, const M4& B) {
+    M4 o;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            o.a[i][j] = 0.;
+            for (int k = 0; k < 4; k++) o.a[i][j] += A.a[i][k] * B.a[k][j];
+        }
+    // the reference rebuilds a Matrix from o, dropping row 3 (:170-183); row 3 of the next operand is again 0,0,0,1
+    o.a[3][0] = 0.; o.a[3][1] = 0.; o.a[3][2] = 0.; o.a[3][3] = 1.;
+    return o;
+}
+void camera_rotation(double pitch, double yaw, double rot[3][3]) {
+    // from_euler_xyz(-pitch, yaw, 0) = a * b * c, matrix.rs:60-72
+    const double x = -pitch, y = yaw, z = 0.;
+    M4 a = {{{1., 0., 0., 0.}, {0., std::cos(x), -std::sin(x), 0.}, {0., std::sin(x), std::cos(x), 0.}, {0., 0., 0., 1.}}};
+    M4 b = {{{std::cos(y), 0., std::sin(y), 0.}, {0., 1., 0., 0.}, {-std::sin(y), 0., std::cos(y), 0.}, {0., 0., 0., 1.}}};
+    M4 cc = {{{std::cos(z), -std::sin(z), 0., 0.}, {std::sin(z), std::cos(z), 0., 0.}, {0., 0., 1., 0.}, {0., 0., 0., 1.}}};
+    M4 r = m4mul(m4mul(a, b), cc);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rot[i][j] = r.a[i][j];
+}
+
+// Re-emits one mesh: DFS-preorder host nodes (rt_bvh_node) -> inner-node array
+// with both children's boxes, triangles in leaf order with precomputed edges.
+int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
+    std::memset(&out, 0, sizeof(out));
+    if (m.n_nodes == 0 || !m.nodes) return fail(c, RT_ERR_INVALID, "mesh without BVH nodes (the reference asserts sbvh.is_some(), mesh.rs:350)");
+    if (m.n_tris == 0 || !m.tri_pos || !m.tri_nrm || !m.verts) return fail(c, RT_ERR_INVALID, "mesh without triangles");
+    if (m.n_prims == 0 || !m.prim_indices) return fail(c, RT_ERR_INVALID, "mesh without leaf primitive list");
+    if (m.n_prims >= 0x7FFFFFFFu) return fail(c, RT_ERR_UNSUPPORTED, "mesh too large");
+    for (uint32_t i = 0; i < 3 * m.n_tris; i++) {
+        if (m.tri_pos[i] >= m.n_verts) return fail(c, RT_ERR_INVALID, "mesh: vertex index out of range");
+        if (m.tri_nrm[i] >= m.n_normals) return fail(c, RT_ERR_INVALID, "mesh: normal index out of range");
+        if (m.tri_uv && m.n_texcoords && m.tri_uv[i] >= m.n_texcoords) return fail(c, RT_ERR_INVALID, "mesh: texcoord index out of range");
+    }
+    // walk the tree iteratively: validate links, number inner nodes, measure depth
+    const uint32_t NN = m.n_nodes;
+    std::vector<uint32_t> inner_id(NN, RT_NONE);
+    std::vector<uint8_t> seen(NN, 0);
+    uint32_t n_inner = 0, max_depth = 0;
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> st;
+        st.push_back({0u, 1u});
+        while (!st.empty()) {
+            auto [i, d] = st.back(); st.pop_back();
+            if (i >= NN || seen[i]) return fail(c, RT_ERR_INVALID, "mesh BVH: bad child link");
+            seen[i] = 1;
+            if (d > max_depth) max_depth = d;
+            const rt_bvh_node& nd = m.nodes[i];
+            if (nd.count == 0) {
+                inner_id[i] = 0;   // numbered below in index order (= DFS pre-order)
+                st.push_back({nd.right_or_first, d + 1});
+                st.push_back({i + 1, d + 1});
+            } else {
+                if ((uint64_t)nd.right_or_first + nd.count > m.n_prims) return fail(c, RT_ERR_INVALID, "mesh BVH: leaf range out of bounds");
+            }
+        }
+    }
+    if (max_depth > RT_MAX_STACK) return fail(c, RT_ERR_UNSUPPORTED, "mesh BVH deeper than the traversal stack (" + std::to_string(max_depth) + " > " + std::to_string(RT_MAX_STACK) + ")");
+    for (uint32_t i = 0; i < NN; i++) if (seen[i] && m.nodes[i].count == 0) inner_id[i] = n_inner++;
+    for (uint32_t i = 0; i < m.n_prims; i++) if (m.prim_indices[i] >= m.n_tris) return fail(c, RT_ERR_INVALID, "mesh BVH: primitive index out of range");
+
+    auto box_of = [&](uint32_t i, double* cen, double* half) {
+        const rt_bvh_node& nd = m.nodes[i];
+        for (int k = 0; k < 3; k++) {
+            cen[k] = (nd.min[k] + nd.max[k]) * 0.5;   // acceleration.rs:76
+            half[k] = nd.max[k] - cen[k];             // acceleration.rs:135
+        }
+    };
+    auto ref_of = [&](uint32_t i) -> uint32_t {
+        const rt_bvh_node& nd = m.nodes[i];
+        return nd.count == 0 ? inner_id[i] : (RT_LEAF_BIT | nd.right_or_first);
+    };
+    std::vector<DNode> nodes(n_inner);
+    std::vector<uint8_t> last(m.n_prims, 0);
+    for (uint32_t i = 0; i < NN; i++) {
+        if (!seen[i]) continue;
+        const rt_bvh_node& nd = m.nodes[i];
+        if (nd.count == 0) {
+            DNode& dn = nodes[inner_id[i]];
+            std::memset(&dn, 0, sizeof(dn));
+            box_of(i + 1, dn.lc, dn.lh);
+            box_of(nd.right_or_first, dn.rc, dn.rh);
+            dn.lref = ref_of(i + 1); dn.rref = ref_of(nd.right_or_first);
+        } else {
+            last[nd.right_or_first + nd.count - 1] = 1;
+        }
+    }
+    std::vector<DTri> tris(m.n_prims);
+    for (uint32_t r = 0; r < m.n_prims; r++) {
+        const uint32_t t = m.prim_indices[r];
+        const double* v0 = &m.verts[3 * (size_t)m.tri_pos[3 * t]];
+        const double* v1 = &m.verts[3 * (size_t)m.tri_pos[3 * t + 1]];
+        const double* v2 = &m.verts[3 * (size_t)m.tri_pos[3 * t + 2]];
+        DTri& dt = tris[r];
+        for (int k = 0; k < 3; k++) { dt.v0[k] = v0[k]; dt.e1[k] = v1[k] - v0[k]; dt.e2[k] = v2[k] - v0[k]; }   // mesh.rs:26-27
+        dt.orig = t; dt.last = last[r];
+    }
+    if (!last[m.n_prims - 1]) return fail(c, RT_ERR_INVALID, "mesh BVH: leaf list does not end on a leaf boundary");
+    box_of(0, out.root_c, out.root_h);
+    out.root_ref = m.nodes[0].count == 0 ? 0u : (RT_LEAF_BIT | m.nodes[0].right_or_first);
+    out.n_inner = n_inner; out.n_tris = m.n_tris; out.n_texcoords = m.tri_uv ? m.n_texcoords : 0;
+    int rc;
+    if ((rc = upload(c, nodes.data(), nodes.size(), &out.nodes)) != RT_OK) return rc;
+    if ((rc = upload(c, tris.data(), tris.size(), &out.tris)) != RT_OK) return rc;
+    if ((rc = upload(c, m.normals, (size_t)m.n_normals * 3, &out.normals)) != RT_OK) return rc;
+    if ((rc = upload(c, m.texcoords, (size_t)m.n_texcoords * 2, &out.texcoords)) != RT_OK) return rc;
+    if ((rc = upload(c, m.tri_nrm, (size_t)m.n_tris * 3, &out.tri_nrm)) != RT_OK) return rc;
+    if (m.tri_uv && m.n_texcoords) { if ((rc = upload(c, m.tri_uv, (size_t)m.n_tris * 3, &out.tri_uv)) != RT_OK) return rc; }
+    return RT_OK;
+}
+
+size_t level_bytes(size_t cap) {
+    // 6+2+3+3 doubles, 2 floats, 6 u32 per slot; each array padded to 256 B
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return 14 * pad(cap * 8) + 2 * pad(cap * 4) + 6 * pad(cap * 4);
+}
+
+int ensure_level(rt_ctx* c, size_t idx, size_t cap) {
+    if (c->levels.size() <= idx) c->levels.resize(idx + 1);
+    LevelAlloc& la = c->levels[idx];
+    if (la.cap >= cap && la.base) return RT_OK;
+    if (la.base) { (void)hipFree(la.base); c->work_bytes -= level_bytes(la.cap); la.base = nullptr; la.cap = 0; }
+    size_t bytes = level_bytes(cap);
+    if (hipMalloc(&la.base, bytes) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes for a wavefront level failed");
+    c->work_bytes += bytes;
+    la.cap = cap;
+    char* p = static_cast<char*>(la.base);
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    auto takeD = [&]() { double* r = reinterpret_cast<double*>(p); p += pad(cap * 8); return r; };
+    auto takeF = [&]() { float* r = reinterpret_cast<float*>(p); p += pad(cap * 4); return r; };
+    auto takeU = [&]() { uint32_t* r = reinterpret_cast<uint32_t*>(p); p += pad(cap * 4); return r; };
+    DLevel& L = la.lv;
+    for (int k = 0; k < 3; k++) L.ro[k] = takeD();
+    for (int k = 0; k < 3; k++) L.rd[k] = takeD();
+    L.hit_t = takeD(); L.hit_t2 = takeD();
+    for (int k = 0; k < 3; k++) L.lit[k] = takeD();
+    L.w_t = takeD(); L.w_r = takeD(); L.emis = takeD();
+    L.hit_u = takeF(); L.hit_v = takeF();
+    L.hit_obj = takeU(); L.hit_prim = takeU(); L.child0 = takeU(); L.child1 = takeU(); L.base_flags = takeU(); L.result = takeU();
+    return RT_OK;
+}
+
+int ensure_buf(rt_ctx* c, void** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *p) return RT_OK;
+    if (*p) { (void)hipFree(*p); c->work_bytes -= *cap; *p = nullptr; *cap = 0; }
+    if (hipMalloc(p, bytes) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipMalloc failed for an output buffer");
+    *cap = bytes; c->work_bytes += bytes;
+    return RT_OK;
+}
+
+ShardMap make_map(int32_t vw, int32_t vh, uint32_t shard, uint32_t n_shards, uint32_t row_major) {
+    ShardMap m;
+    m.shard = shard; m.n_shards = n_shards;
+    m.tiles_x = (uint32_t)((vw + RT_TILE_W - 1) / RT_TILE_W);
+    m.n_tiles = m.tiles_x * (uint32_t)((vh + RT_TILE_H - 1) / RT_TILE_H);
+    m.row_major_out = row_major;
+    return m;
+}
+
+uint64_t valid_pixels(const ShardMap& m, int32_t vw, int32_t vh) {
+    uint64_t n = 0;
+    for (uint64_t gid = m.shard; gid < m.n_tiles; gid += m.n_shards) {
+        uint32_t tx = (uint32_t)(gid % m.tiles_x), ty = (uint32_t)(gid / m.tiles_x);
+        int32_t w = std::min<int32_t>(RT_TILE_W, vw - (int32_t)tx * RT_TILE_W);
+        int32_t h = std::min<int32_t>(RT_TILE_H, vh - (int32_t)ty * RT_TILE_H);
+        n += (uint64_t)w * (uint64_t)h;
+    }
+    return n;
+}
+
+// The frame: levels 0..max_depth forward, then folded back.
+int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st) {
+    if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int64_t n0s = rt_shard_pixels(c->vw, c->vh, shard, n_shards);
+    if (n0s < 0) return fail(c, RT_ERR_INVALID, "bad shard arguments");
+    if ((uint64_t)n0s >= 0x7FFFFFFFull) return fail(c, RT_ERR_UNSUPPORTED, "frame too large for one shard");
+    const uint32_t n0 = (uint32_t)n0s;
+    ShardMap map = make_map(c->vw, c->vh, shard, n_shards, row_major);
+    rt_stats stats; std::memset(&stats, 0, sizeof(stats));
+    stats.rays_primary = valid_pixels(map, c->vw, c->vh);
+    stats.rays_per_level[0] = stats.rays_primary;
+    hipStream_t s = c->stream;
+    std::memset(c->hcounters, 0, sizeof(DCounters));
+    HIP_TRY(c, hipMemsetAsync(c->dcounters, 0, sizeof(DCounters), s));
+
+    std::vector<uint32_t> counts;
+    counts.push_back(n0);
+    float ms_trace = 0.f, ms_shade = 0.f, ms_resolve = 0.f;
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    int rc;
+    if (n0 > 0) {
+        if ((rc = ensure_level(c, 0, n0)) != RT_OK) return rc;
+        hipLaunchKernelGGL(k_primary, dim3((n0 + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, c->dscene, c->levels[0].lv, n0, map);
+    }
+    for (uint32_t depth = 0; depth < counts.size(); depth++) {
+        const uint32_t n = counts[depth];
+        if (n == 0) break;
+        // worst case every ray spawns two children (scene.rs:134-172)
+        const bool can_spawn = depth < c->max_depth;
+        const size_t next_cap = can_spawn ? std::min<size_t>((size_t)2 * n, 0x7FFFFFFEull) : 1;
+        if ((rc = ensure_level(c, depth + 1, next_cap)) != RT_OK) return rc;
+        const dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
+        HIP_TRY(c, hipEventRecord(c->ev[1], s));
+        hipLaunchKernelGGL(k_trace, grid, block, 0, s, c->dscene, c->levels[depth].lv, n);
+        HIP_TRY(c, hipEventRecord(c->ev[2], s));
+        hipLaunchKernelGGL(k_shade, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, depth,
+                           (uint32_t)next_cap, c->dcounters, depth == 0 ? d_ids : nullptr, map);
+        HIP_TRY(c, hipEventRecord(c->ev[3], s));
+        HIP_TRY(c, hipMemcpyAsync(c->hcounters, c->dcounters, sizeof(DCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, hipGetLastError());
+        float a = 0.f, b = 0.f;
+        (void)hipEventElapsedTime(&a, c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&b, c->ev[2], c->ev[3]);
+        ms_trace += a; ms_shade += b;
+        const unsigned long long spawned = c->hcounters->next_count;
+        if (spawned > next_cap) return fail(c, RT_ERR_DEVICE, "wavefront level overflow");
+        if (spawned > 0 && can_spawn) {
+            counts.push_back((uint32_t)spawned);
+            if (depth + 1 < 8) stats.rays_per_level[depth + 1] = spawned;
+        }
+        // children of this level were appended at [0, spawned) of the next level: restart its counter
+        HIP_TRY(c, hipMemsetAsync(&c->dcounters->next_count, 0, sizeof(unsigned long long), s));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[4], s));
+    for (int depth = (int)counts.size() - 1; depth >= 0; depth--) {
+        const uint32_t n = counts[depth];
+        if (n == 0) continue;
+        hipLaunchKernelGGL(k_resolve, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, c->dscene, c->levels[depth].lv,
+                           c->levels[depth + 1].lv, n, depth == 0 ? 1 : 0, d_rgb, map);
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[5], s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipGetLastError());
+    (void)hipEventElapsedTime(&ms_resolve, c->ev[4], c->ev[5]);
+    float ms_all = 0.f;
+    (void)hipEventElapsedTime(&ms_all, c->ev[0], c->ev[5]);
+    stats.rays_reflect = c->hcounters->rays_reflect;
+    stats.rays_transmit = c->hcounters->rays_transmit;
+    stats.rays_shadow = c->hcounters->rays_shadow;
+    stats.ms_render = ms_all; stats.ms_trace = ms_trace; stats.ms_shade = ms_shade; stats.ms_resolve = ms_resolve;
+    stats.ms_upload = c->ms_upload;
+    stats.device_bytes = c->scene_bytes + c->work_bytes;
+    if (st) *st = stats;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t rt_shard_pixels(int32_t vw, int32_t vh, uint32_t shard, uint32_t n_shards) {
+    if (vw <= 0 || vh <= 0 || n_shards == 0 || shard >= n_shards) return -1;
+    const uint64_t tiles = (uint64_t)((vw + RT_TILE_W - 1) / RT_TILE_W) * (uint64_t)((vh + RT_TILE_H - 1) / RT_TILE_H);
+    const uint64_t mine = shard < tiles ? (tiles - shard + n_shards - 1) / n_shards : 0;
+    return (int64_t)(mine * RT_TILE_W * RT_TILE_H);
+}
+
+int rt_ctx_create(int device_id, rt_ctx** out) {
+    if (!out) { g_create_error = "rt_ctx_create: out is NULL"; return RT_ERR_INVALID; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_create_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"); return RT_ERR_DEVICE; }
+    if (device_id < 0 || device_id >= n) { g_create_error = "device id out of range"; return RT_ERR_INVALID; }
+    rt_ctx* c = new (std::nothrow) rt_ctx();
+    if (!c) { g_create_error = "out of host memory"; return RT_ERR_NOMEM; }
+    c->device = device_id;
+    auto bail = [&](const char* what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); delete c; return RT_ERR_DEVICE; };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipMalloc((void**)&c->dscene, sizeof(DScene))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&c->dcounters, sizeof(DCounters))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipHostMalloc((void**)&c->hcounters, sizeof(DCounters), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    for (auto& ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    *out = c;
+    return RT_OK;
+}
+
+void rt_ctx_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    for (auto& la : c->levels) if (la.base) (void)hipFree(la.base);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_ids) (void)hipFree(c->d_ids);
+    if (c->d_ids2) (void)hipFree(c->d_ids2);
+    if (c->dscene) (void)hipFree(c->dscene);
+    if (c->dcounters) (void)hipFree(c->dcounters);
+    if (c->hcounters) (void)hipHostFree(c->hcounters);
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int rt_scene_upload(rt_ctx* c, const rt_scene_desc* d) {
+    if (!c) return RT_ERR_INVALID;
+    if (!d) return fail(c, RT_ERR_INVALID, "scene is NULL");
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    if (d->camera.vw <= 0 || d->camera.vh <= 0) return fail(c, RT_ERR_INVALID, "camera: vw and vh must be positive");
+    if ((uint64_t)d->camera.vw * (uint64_t)d->camera.vh >= 0x7FFFFFFFull) return fail(c, RT_ERR_UNSUPPORTED, "frame larger than 2^31 pixels");
+    if (d->options.max_ray_depth > 7) return fail(c, RT_ERR_UNSUPPORTED, "max_ray_depth above 7 is not supported");
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+        if (d->lights[i].kind == RT_LIGHT_AREA) return fail(c, RT_ERR_UNSUPPORTED, "area lights draw from an unseeded RNG (lighting/area.rs:121) and are not rendered on the device");
+        if (d->lights[i].kind > RT_LIGHT_AREA) return fail(c, RT_ERR_INVALID, "unknown light kind");
+    }
+    for (uint32_t i = 0; i < d->n_materials; i++)
+        if (d->materials[i].texture >= d->n_textures) return fail(c, RT_ERR_INVALID, "material: texture index out of range");
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rt_texture& t = d->textures[i];
+        if (t.kind > RT_TEX_CHECKER) return fail(c, RT_ERR_INVALID, "unknown texture kind");
+        if (t.kind == RT_TEX_IMAGE && (!t.rgb || t.w == 0 || t.h == 0)) return fail(c, RT_ERR_INVALID, "image texture without pixels");
+    }
+    DScene& H = c->hscene;
+    std::memset(&H, 0, sizeof(H));
+    for (int k = 0; k < 3; k++) H.cam_o[k] = d->camera.origin[k];
+    camera_rotation(d->camera.pitch, d->camera.yaw, H.rot);
+    H.half_w = (double)d->camera.vw * 0.5;               // camera.rs:63
+    H.half_h = (double)d->camera.vh * 0.5;               // :64
+    H.cam_z = (double)d->camera.vh * 0.5 * d->camera.chf;   // :65
+    H.vw = d->camera.vw; H.vh = d->camera.vh;
+    H.max_depth = d->options.max_ray_depth;
+    for (int k = 0; k < 3; k++) H.ambient[k] = (double)d->options.ambient[k] / 255.;   // vector.rs:216-224
+    H.n_objects = d->n_objects; H.n_lights = d->n_lights; H.n_meshes = d->n_meshes;
+
+    int rc;
+    // textures: one device copy per distinct host pixel pointer
+    std::map<const uint8_t*, const uint8_t*> pix;
+    std::vector<DMaterial> mats(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const rt_material& m = d->materials[i];
+        const rt_texture& t = d->textures[m.texture];
+        DMaterial& dm = mats[i];
+        std::memset(&dm, 0, sizeof(dm));
+        dm.tex_kind = t.kind; dm.a_rgb = pack_rgb(t.a); dm.b_rgb = pack_rgb(t.b);
+        if (t.kind == RT_TEX_IMAGE) {
+            dm.tex_w = t.w; dm.tex_h = t.h;
+            auto it = pix.find(t.rgb);
+            if (it == pix.end()) {
+                const uint8_t* dp = nullptr;
+                if ((rc = upload(c, t.rgb, (size_t)t.w * t.h * 3, &dp)) != RT_OK) return rc;
+                it = pix.emplace(t.rgb, dp).first;
+            }
+            dm.tex_rgb = it->second;
+        }
+        dm.reflectiveness = m.reflectiveness; dm.transparency = m.transparency; dm.ior = m.ior; dm.emissivity = m.emissivity;
+    }
+    if ((rc = upload(c, mats.data(), mats.size(), &H.materials)) != RT_OK) return rc;
+
+    std::vector<DMesh> meshes(d->n_meshes);
+    for (uint32_t i = 0; i < d->n_meshes; i++)
+        if ((rc = upload_mesh(c, d->meshes[i], meshes[i])) != RT_OK) return rc;
+    if ((rc = upload(c, meshes.data(), meshes.size(), &H.meshes)) != RT_OK) return rc;
+
+    std::vector<DObject> objs(d->n_objects);
+    for (uint32_t i = 0; i < d->n_objects; i++) {
+        const rt_object& o = d->objects[i];
+        if (o.material >= d->n_materials) return fail(c, RT_ERR_INVALID, "object: material index out of range");
+        const uint32_t lim = o.kind == RT_OBJ_SPHERE ? d->n_spheres : o.kind == RT_OBJ_PLANE ? d->n_planes
+                           : o.kind == RT_OBJ_BOX ? d->n_boxes : o.kind == RT_OBJ_MESH ? d->n_meshes : 0;
+        if (o.kind > RT_OBJ_MESH || o.payload >= lim) return fail(c, RT_ERR_INVALID, "object: bad kind or payload index");
+        const rt_material& m = d->materials[o.material];
+        objs[i].kind = o.kind; objs[i].material = o.material; objs[i].payload = o.payload;
+        objs[i].need_far = (o.kind == RT_OBJ_MESH && m.transparency > RT_EPSILON && m.ior == 1.) ? 1u : 0u;
+    }
+    if ((rc = upload(c, objs.data(), objs.size(), &H.objects)) != RT_OK) return rc;
+
+    std::vector<double> sph((size_t)d->n_spheres * 4), pln((size_t)d->n_planes * 8), bxs((size_t)d->n_boxes * 6);
+    for (uint32_t i = 0; i < d->n_spheres; i++) { for (int k = 0; k < 3; k++) sph[4 * i + k] = d->spheres[i].c[k]; sph[4 * i + 3] = d->spheres[i].r; }
+    for (uint32_t i = 0; i < d->n_planes; i++) {
+        for (int k = 0; k < 3; k++) { pln[8 * i + k] = d->planes[i].p0[k]; pln[8 * i + 3 + k] = d->planes[i].n[k]; }
+        pln[8 * i + 6] = (double)d->planes[i].uv_wrap; pln[8 * i + 7] = 0.;
+    }
+    for (uint32_t i = 0; i < d->n_boxes; i++) for (int k = 0; k < 3; k++) { bxs[6 * i + k] = d->boxes[i].pos[k]; bxs[6 * i + 3 + k] = d->boxes[i].half[k]; }
+    if ((rc = upload(c, sph.data(), sph.size(), &H.spheres)) != RT_OK) return rc;
+    if ((rc = upload(c, pln.data(), pln.size(), &H.planes)) != RT_OK) return rc;
+    if ((rc = upload(c, bxs.data(), bxs.size(), &H.boxes)) != RT_OK) return rc;
+
+    std::vector<DLight> lights(d->n_lights);
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+        const rt_light& l = d->lights[i];
+        DLight& dl = lights[i];
+        std::memset(&dl, 0, sizeof(dl));
+        dl.kind = l.kind; dl.specular_power = l.specular_power; dl.shadows = l.shadows;
+        for (int k = 0; k < 3; k++) { dl.col[k] = (double)l.color[k] / 255.; dl.v[k] = l.v[k]; }
+        dl.intensity = l.intensity; dl.specular_strength = l.specular_strength;
+        dl.shadow_coefficient = l.shadow_coefficient; dl.max_distance = l.max_distance;
+    }
+    if ((rc = upload(c, lights.data(), lights.size(), &H.lights)) != RT_OK) return rc;
+
+    H.sky_kind = d->skybox.kind; H.sky_rgb = pack_rgb(d->skybox.color);
+    if (d->skybox.kind > RT_SKY_CUBEMAP) return fail(c, RT_ERR_INVALID, "unknown skybox kind");
+    if (d->skybox.kind == RT_SKY_CUBEMAP) {
+        if (!d->skybox.rgb || d->skybox.w < 4 || d->skybox.w / 4 != d->skybox.h / 3) return fail(c, RT_ERR_INVALID, "cubemap: width/4 must equal height/3 (skybox.rs:49-51)");
+        H.sky_w = d->skybox.w; H.sky_h = d->skybox.h;
+        if ((rc = upload(c, d->skybox.rgb, (size_t)d->skybox.w * d->skybox.h * 3, &H.sky_pix)) != RT_OK) return rc;
+    }
+    HIP_TRY(c, hipMemcpy(c->dscene, &H, sizeof(DScene), hipMemcpyHostToDevice));
+    c->vw = H.vw; c->vh = H.vh; c->max_depth = H.max_depth;
+    c->have_scene = true;
+    c->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+int rt_render(rt_ctx* c, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* stats_out) {
+    if (!c) return RT_ERR_INVALID;
+    if (!rgb_out) return fail(c, RT_ERR_INVALID, "rgb_out is NULL");
+    if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t px = (size_t)c->vw * (size_t)c->vh;
+    const int64_t slots = rt_shard_pixels(c->vw, c->vh, 0, 1);
+    int rc;
+    if ((rc = ensure_buf(c, &c->d_out, &c->d_out_cap, px * 3)) != RT_OK) return rc;
+    if (prim_id_out) {
+        if ((rc = ensure_buf(c, &c->d_ids, &c->d_ids_cap, (size_t)slots * 8)) != RT_OK) return rc;
+        if ((rc = ensure_buf(c, &c->d_ids2, &c->d_ids2_cap, px * 8)) != RT_OK) return rc;
+    }
+    rt_stats st;
+    rc = render_frame(c, 0, 1, 1, static_cast<uint8_t*>(c->d_out), prim_id_out ? static_cast<uint32_t*>(c->d_ids) : nullptr, &st);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(rgb_out, c->d_out, px * 3, hipMemcpyDeviceToHost, c->stream));
+    if (prim_id_out) {
+        ShardMap map = make_map(c->vw, c->vh, 0, 1, 1);
+        hipLaunchKernelGGL(k_ids_rowmajor, dim3(((uint32_t)slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->dscene,
+                           static_cast<const uint32_t*>(c->d_ids), static_cast<uint32_t*>(c->d_ids2), (uint32_t)slots, map);
+        HIP_TRY(c, hipMemcpyAsync(prim_id_out, c->d_ids2, px * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    st.device_bytes = c->scene_bytes + c->work_bytes;
+    if (stats_out) *stats_out = st;
+    return RT_OK;
+}
+
+int rt_render_shard(rt_ctx* c, uint32_t shard, uint32_t n_shards, void* d_rgb, void* d_ids, rt_stats* stats_out) {
+    if (!c) return RT_ERR_INVALID;
+    if (!d_rgb) return fail(c, RT_ERR_INVALID, "d_rgb is NULL");
+    if (n_shards == 0 || shard >= n_shards) return fail(c, RT_ERR_INVALID, "bad shard arguments");
+    auto t0 = std::chrono::steady_clock::now();
+    rt_stats st;
+    int rc = render_frame(c, shard, n_shards, 0, static_cast<uint8_t*>(d_rgb), static_cast<uint32_t*>(d_ids), &st);
+    if (rc != RT_OK) return rc;
+    st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (stats_out) *stats_out = st;
+    return RT_OK;
+}
+
+int rt_detile(rt_ctx* c, const void* d_gathered, uint32_t n_shards, int64_t slots_per_shard, uint32_t elem_bytes, void* d_image) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
+    if (!d_gathered || !d_image || n_shards == 0 || slots_per_shard <= 0 || (elem_bytes != 3 && elem_bytes != 8)) return fail(c, RT_ERR_INVALID, "rt_detile: bad arguments");
+    for (uint32_t s = 0; s < n_shards; s++)
+        if (rt_shard_pixels(c->vw, c->vh, s, n_shards) > slots_per_shard) return fail(c, RT_ERR_INVALID, "rt_detile: slots_per_shard smaller than a shard");
+    HIP_TRY(c, hipSetDevice(c->device));
+    ShardMap map = make_map(c->vw, c->vh, 0, n_shards, 1);
+    const unsigned long long total = (unsigned long long)slots_per_shard * n_shards;
+    if (total >= (1ull << 40)) return fail(c, RT_ERR_UNSUPPORTED, "rt_detile: too many slots");
+    hipLaunchKernelGGL(k_detile, dim3((unsigned)((total + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, c->stream, static_cast<const uint8_t*>(d_gathered),
+                       static_cast<uint8_t*>(d_image), c->vw, c->vh, n_shards, (unsigned long long)slots_per_shard, elem_bytes, map.tiles_x, map.n_tiles);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_cast_rays(rt_ctx* c, uint32_t n, const double* origins, const double* dirs, rt_ray_hit* hits_out) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
+    if (n == 0) return RT_OK;
+    if (!origins || !dirs || !hits_out) return fail(c, RT_ERR_INVALID, "rt_cast_rays: NULL argument");
+    static_assert(sizeof(DProbeHit) == sizeof(rt_ray_hit), "probe record layout");
+    HIP_TRY(c, hipSetDevice(c->device));
+    double *d_o = nullptr, *d_d = nullptr; DProbeHit* d_h = nullptr;
+    int rc = RT_OK;
+    if (hipMalloc((void**)&d_o, (size_t)n * 24) != hipSuccess || hipMalloc((void**)&d_d, (size_t)n * 24) != hipSuccess ||
+        hipMalloc((void**)&d_h, (size_t)n * sizeof(DProbeHit)) != hipSuccess) {
+        rc = fail(c, RT_ERR_NOMEM, "rt_cast_rays: hipMalloc failed");
+    } else {
+        hipError_t e = hipMemcpy(d_o, origins, (size_t)n * 24, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_d, dirs, (size_t)n * 24, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_probe, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->dscene, d_o, d_d, d_h, n);
+            e = hipStreamSynchronize(c->stream);
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(hits_out, d_h, (size_t)n * sizeof(DProbeHit), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, RT_ERR_DEVICE, std::string("rt_cast_rays: ") + hipGetErrorString(e));
+    }
+    if (d_o) (void)hipFree(d_o);
+    if (d_d) (void)hipFree(d_d);
+    if (d_h) (void)hipFree(d_h);
+    return rc;
+}
+
+}  // extern "C"

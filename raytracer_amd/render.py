@@ -1,0 +1,69 @@
+"""Handle on one rt_ctx of librtgpu.so (include/rtgpu.h): upload a flat scene,
+render frames, render image-space shards into device memory, probe rays."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class Context:
+    def __init__(self, device_id=0):
+        self._c = C.c_void_p()
+        rc = N.gpu().rt_ctx_create(int(device_id), C.byref(self._c))
+        if rc != N.RT_OK:
+            raise N.RtError(rc, N.gpu().rt_last_error(None).decode(errors="replace"))
+        self.device_id = device_id
+        self.vw = self.vh = 0
+
+    def close(self):
+        if self._c:
+            N.gpu().rt_ctx_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != N.RT_OK:
+            raise N.RtError(rc, N.gpu().rt_last_error(self._c).decode(errors="replace"))
+
+    def upload(self, scene):
+        """scene: anything with .flatten() -> rt_scene_desc address (Scene, LoadedScene)"""
+        from .scene import desc_info
+        p = scene.flatten()
+        self._check(N.gpu().rt_scene_upload(self._c, p))
+        info = desc_info(p)
+        self.vw, self.vh = info["vw"], info["vh"]
+        return self
+
+    def render(self, ids=False):
+        """rt_render -> (rgb (vh, vw, 3) u8, ids (vh, vw, 2) u32 or None, RtStats)"""
+        rgb = np.empty((self.vh, self.vw, 3), dtype=np.uint8)
+        idb = np.empty((self.vh, self.vw, 2), dtype=np.uint32) if ids else None
+        st = N.RtStats()
+        self._check(N.gpu().rt_render(self._c, rgb.ctypes.data, idb.ctypes.data if ids else None, C.byref(st)))
+        return rgb, idb, st
+
+    def shard_pixels(self, shard, n_shards):
+        return N.gpu().rt_shard_pixels(self.vw, self.vh, shard, n_shards)
+
+    def render_shard(self, shard, n_shards, d_rgb_ptr, d_ids_ptr=None):
+        """rt_render_shard into device memory (raw device addresses, e.g. tensor.data_ptr())"""
+        st = N.RtStats()
+        self._check(N.gpu().rt_render_shard(self._c, shard, n_shards, C.c_void_p(d_rgb_ptr),
+                                            C.c_void_p(d_ids_ptr) if d_ids_ptr else None, C.byref(st)))
+        return st
+
+    def detile(self, d_gathered_ptr, n_shards, slots_per_shard, elem_bytes, d_image_ptr):
+        self._check(N.gpu().rt_detile(self._c, C.c_void_p(d_gathered_ptr), n_shards, slots_per_shard, elem_bytes, C.c_void_p(d_image_ptr)))
+
+    def cast_rays(self, origins, dirs):
+        o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        hits = (N.RtRayHit * len(o))()
+        self._check(N.gpu().rt_cast_rays(self._c, len(o), o.ctypes.data, d.ctypes.data, hits))
+        return hits

@@ -1,0 +1,232 @@
+"""The benchmark / parity scenes, built through the Scene API with the values
+the reference's SDL interpreter would hand over (defaults and normalisations
+of sdl/src/interpret.rs:604-1078).  `random()` calls are replaced by seeded
+draws and missing assets by procedural stand-ins; each builder says where.
+"""
+import math
+import os
+
+import numpy as np
+
+from .scene import (Aabb, Area, Camera, Material, Mesh, Plane, Point, Scene, Sphere, Sun, Texture)
+
+
+def normalize(v):
+    """Vector3::normalize (vector.rs:74-81) with the reference's operation order"""
+    x, y, z = (float(c) for c in v)
+    m = math.sqrt(x * x + y * y + z * z)
+    return (x / m, y / m, z / m)
+
+
+def as_u8(x):
+    """Rust `f64 as u8` (interpret.rs:1249): truncate, saturate, NaN -> 0"""
+    if not (x > 0.0):
+        return 0
+    return 255 if x >= 255.0 else int(x)
+
+
+def sdl_material(texture=None, reflectiveness=0., transparency=0., ior=1.5, emissivity=0.):
+    """a `material: {..}` dictionary (interpret.rs:1052-1073): ior defaults to 1.5 there"""
+    return Material(texture or Texture.solid((255, 255, 255)), reflectiveness, transparency, ior, emissivity)
+
+
+def sdl_sun(vector, **kw):
+    return Sun(vector=normalize(vector), **kw)        # interpret.rs:949-951
+
+
+def sdl_plane(origin, normal=(0., 1., 0.), material=None, uv_wrap=1.):
+    return Plane(origin, normalize(normal), material or Material(), uv_wrap)   # interpret.rs:860-867
+
+
+def procedural_cubemap(cell, seed=1):
+    """Stand-in atlas (4*cell x 3*cell) for cubemap images that cannot travel or are missing."""
+    rng = np.random.default_rng(seed)
+    h, w = 3 * cell, 4 * cell
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.empty((h, w, 3), dtype=np.uint8)
+    img[..., 0] = (40 + 60 * (xx // cell) + (yy % cell) * 50 // cell) % 256
+    img[..., 1] = (30 + 70 * (yy // cell) + (xx % cell) * 60 // cell) % 256
+    img[..., 2] = 90 + rng.integers(0, 80, size=(h, w))
+    stars = rng.random((h, w)) < 0.02
+    img[stars] = (255, 240, 220)
+    return img
+
+
+def loop_scene(vw=800, vh=600):
+    """README.md:253-274 == scenes/loop.sdl at the default 800x600 camera: 16 grey
+    spheres on a ring, one default sun, default Normal skybox."""
+    s = Scene()
+    s.set_camera(Camera(vw=vw, vh=vh))
+    s.add_light(sdl_sun((-0.8, -1., -0.2)))
+    segments = 16
+    for i in range(segments):
+        frac = i / segments
+        inner = frac * math.tau
+        cc = as_u8(frac * 255)
+        s.add(Sphere((math.cos(inner), math.sin(inner), -4.), 0.3, sdl_material(Texture.solid((cc, cc, cc)))))
+    return s
+
+
+def refraction_scene(vw=1920, vh=1080, cubemap=None):
+    """scenes/refraction.sdl (config 2).  `plane{vector:..}` is ignored by the
+    interpreter (the property is called `normal`), so the plane keeps (0,1,0)."""
+    s = Scene()
+    s.add_light(sdl_sun((-0.8, -1., -0.2)))
+    s.add(sdl_plane((0., -1., 0.)))
+    s.set_camera(Camera(vw=vw, vh=vh, yaw=0.0001, pitch=0.0002))
+    s.skybox_cubemap(cubemap if cubemap is not None else procedural_cubemap(256))
+    s.add(Sphere((0., 0., -5.), 1., sdl_material(transparency=0.6, reflectiveness=0.5)))
+    s.add(Sphere((-1., 0., -9.), 1., sdl_material(Texture.solid((255, 0, 0)), reflectiveness=0.2)))
+    s.add(Sphere((1.0, 0., -9.), 1., sdl_material(Texture.solid((0, 0, 255)), reflectiveness=0.2)))
+    return s
+
+
+def cornell_scene(vw=1920, vh=1080):
+    """scenes/cornell.sdl (config 1; has an area light => CPU path only)"""
+    s = Scene()
+    s.set_camera(Camera(vw=vw, vh=vh, origin=(0., 0., 3.), fov=45.))
+    s.add(Aabb((0., 1., 0.), (0.2, 0.0001, 0.2), sdl_material(emissivity=1.)))
+    s.add_light(Area(surface="rectangle", corners=[(-0.25, 0.95, -0.25), (-0.25, 0.95, 0.25), (0.25, 0.95, -0.25), (0.25, 0.95, 0.25)],
+                     iterations=64, intensity=0.12))
+    s.add(sdl_plane((0., -1., 0.), (0., 1., 0.)))
+    s.add(sdl_plane((0., 1., 0.), (0., -1., 0.)))
+    s.add(sdl_plane((0., 0., -1.), (0., 0., 1.)))
+    s.add(sdl_plane((-1., 0., 0.), (1., 0., 0.), sdl_material(Texture.solid((255, 0, 0)))))
+    s.add(sdl_plane((1., 0., 0.), (-1., 0., 0.), sdl_material(Texture.solid((0, 255, 0)))))
+    s.add(Sphere((-0.1, -0.6, 0.4), 0.4, sdl_material(transparency=0.6, reflectiveness=0.5)))
+    s.add(Sphere((0.3, -0.5, -0.4), 0.5, sdl_material(Texture.solid((0, 0, 255)))))
+    return s
+
+
+def sdl_mesh(mesh, position=(0., 0., 0.), scale=1., rotate_xyz=None, rotate_zyx=None, recenter=True):
+    """the mesh pipeline of interpret.rs:822-855"""
+    if scale != 1.:
+        mesh.scale(scale)
+    if recenter:
+        mesh.center()
+    if rotate_xyz is not None:
+        mesh.rotate_xyz(rotate_xyz)
+    if rotate_zyx is not None:
+        mesh.rotate_zyx(rotate_zyx)
+    if tuple(position) != (0., 0., 0.):
+        mesh.shift(position)
+    if mesh.n_normals == 0:
+        mesh.recalculate_normals()
+    mesh.generate_sbvh()
+    return mesh
+
+
+def fedora_scene(obj_path, texture_pixels, vw=3840, vh=2160, cubemap=None):
+    """scenes/fedora.sdl (config 3): textured 1038-triangle mesh over a reflective plane"""
+    s = Scene()
+    s.set_camera(Camera(vw=vw, vh=vh, origin=(1.5, 0.3, 3.), yaw=-0.5, pitch=-0.3))
+    s.skybox_cubemap(cubemap if cubemap is not None else procedural_cubemap(256))
+    s.add_light(sdl_sun((-0.8, -1., -0.3), intensity=0.8, specular_power=64))
+    mesh = Mesh.from_obj(obj_path, sdl_material(Texture.image(texture_pixels)))
+    sdl_mesh(mesh, position=(0., -0.5, 0.))
+    s.add(mesh)
+    s.add(sdl_plane((0., -1., 0.), material=sdl_material(reflectiveness=0.6)))
+    return s
+
+
+def teapot_scene(obj_path, vw=3840, vh=2160, seed=1):
+    """scenes/bunny.sdl with assets/teapot.obj standing in for the missing
+    bunny.obj; its three random() angles (bunny.sdl:15-19) come from `seed`."""
+    rng = np.random.default_rng(seed)
+    rot = tuple(float(a) for a in rng.uniform(0., 2. * math.pi, 3))
+    s = Scene()
+    s.set_camera(Camera(vw=vw, vh=vh))
+    s.add_light(sdl_sun((-0.4, -1., -0.2), intensity=0.6))
+    mesh = Mesh.from_obj(obj_path, sdl_material(Texture.solid((0, 180, 255))))
+    sdl_mesh(mesh, position=(0., 0., -10.), scale=2., rotate_xyz=rot)
+    s.add(mesh)
+    return s
+
+
+def synthetic_terrain_scene(vw=3840, vh=2160, cells=708, n_lights=8, seed=42):
+    """Config 4: a cells x cells fBm height field (2*cells^2 triangles; 708 ->
+    1,002,528), reflective 0.3, one glass sphere above it, `n_lights` point
+    lights on a ring, solid skybox, camera looking down ~30 degrees."""
+    s = Scene()
+    extent = float(cells)
+    mesh = Mesh.heightfield(cells, cells, cell=1.0, amplitude=extent * 0.02, base_freq=8.0 / extent, octaves=3, seed=seed,
+                            material=sdl_material(Texture.solid((200, 190, 170)), reflectiveness=0.3))
+    sdl_mesh(mesh, position=(0., 0., 0.))           # recentred on the origin
+    s.add(mesh)
+    s.add(Sphere((0., extent * 0.06, 0.), extent * 0.04, sdl_material(transparency=0.6, reflectiveness=0.5)))
+    s.skybox_solid((30, 40, 70))
+    ring_r, ring_h = extent * 0.28, extent * 0.085
+    for k in range(n_lights):
+        a = 2. * math.pi * k / max(n_lights, 1)
+        pos = (ring_r * math.cos(a), ring_h, ring_r * math.sin(a))
+        d_centre = math.sqrt(pos[0] ** 2 + pos[1] ** 2 + pos[2] ** 2)
+        # I / (d/2)^2 ~ 0.5 at the terrain centre (point.rs:102)
+        s.add_light(Point(position=pos, intensity=0.5 * (d_centre / 2.) ** 2 / max(n_lights / 4., 1.), max_distance=1e9))
+    cam_h = extent * 0.25
+    s.set_camera(Camera(vw=vw, vh=vh, origin=(0.0001, cam_h, extent * 0.55), yaw=0.0001, pitch=-0.5236))
+    return s
+
+
+def huge_grid_scene(vw=7680, vh=4320, n=12, seed=7, cubemap=None):
+    """scenes/huge_grid.sdl (config 5): n^3 jittered glass spheres; the jitter's
+    random() (huge_grid.sdl:31) comes from `seed`; assets/space.png is missing,
+    so a procedural atlas stands in."""
+    rng = np.random.default_rng(seed)
+    spacing, radius, jitter = 2., 0.5, 0.45
+    s = Scene()
+    s.add_light(sdl_sun((-0.8, -1., -0.2), shadows=True))
+    s.skybox_cubemap(cubemap if cubemap is not None else procedural_cubemap(256, seed=3))
+    s.set_camera(Camera(vw=vw, vh=vh, origin=(4.6, 0.8, 9.), yaw=-0.4, pitch=-0.2))
+    hn = n * 0.5
+    for z in range(n):
+        for y in range(n):
+            for x in range(n):
+                j = rng.uniform(-jitter, jitter, 3)
+                pos = ((x - hn) * spacing + float(j[0]), (y - hn) * spacing + float(j[1]), (z - hn) * spacing + float(j[2]))
+                col = (as_u8(x / n * 255), as_u8(y / n * 255), as_u8(z / n * 255))
+                s.add(Sphere(pos, radius, sdl_material(Texture.solid(col), transparency=0.4, reflectiveness=0.5)))
+    return s
+
+
+def terrain_scene(vw=7680, vh=4320, w=72, h=72, seed=11, cubemap=None):
+    """scenes/terrain.sdl (config 5): (w-1)*(h-1)*2 triangles, reflectiveness 0.8.
+    Heights come from this module's seeded value noise (the reference's `perlin`
+    is an un-vendored dependency, so the exact heights are not reproducible)."""
+    s = Scene()
+    s.skybox_cubemap(cubemap if cubemap is not None else procedural_cubemap(256, seed=3))
+    s.add_light(sdl_sun((-0.8, -1., -0.2)))
+    s.set_camera(Camera(vw=vw, vh=vh, origin=(-4., 2., 6.), yaw=0.3, pitch=-0.3))
+    mesh = Mesh.heightfield(w - 1, h - 1, cell=1.0, amplitude=2.0, base_freq=0.08, octaves=3, seed=seed,
+                            material=sdl_material(reflectiveness=0.8))
+    sdl_mesh(mesh, position=(0., -3., -5.))
+    s.add(mesh)
+    return s
+
+
+def small_mixed_scene(vw=160, vh=120, cells=24, seed=5):
+    """A small scene touching every device code path: mesh (reflective), glass
+    sphere (refraction + fresnel mix), see-through box (ior 1), checker plane,
+    emissive box, sun + two point lights, cubemap skybox."""
+    s = Scene()
+    s.set_camera(Camera(vw=vw, vh=vh, origin=(0.3, 2.5, 9.), yaw=0.05, pitch=-0.2, fov=60.))
+    s.skybox_cubemap(procedural_cubemap(32, seed=seed))
+    s.add_light(sdl_sun((-0.6, -1., -0.3)))
+    s.add_light(Point(position=(3., 4., 2.), intensity=8.))
+    s.add_light(Point(position=(-4., 3., 1.), intensity=5., color=(255, 200, 160)))
+    mesh = Mesh.heightfield(cells, cells, cell=0.5, amplitude=0.6, base_freq=0.3, octaves=3, seed=seed,
+                            material=sdl_material(Texture.solid((180, 200, 160)), reflectiveness=0.3))
+    sdl_mesh(mesh, position=(0., -0.5, 0.))
+    s.add(mesh)
+    s.add(sdl_plane((0., -2., 0.), material=sdl_material(Texture.checkerboard((255, 255, 255), (60, 60, 60)), reflectiveness=0.2), uv_wrap=2.))
+    s.add(Sphere((0., 1.5, 1.), 1., sdl_material(transparency=0.6, reflectiveness=0.5)))
+    s.add(Sphere((-2.5, 1.0, 0.), 0.8, sdl_material(Texture.solid((255, 40, 40)), reflectiveness=0.4)))
+    s.add(Aabb((2.5, 0.8, 0.5), (0.7, 0.7, 0.7), sdl_material(Texture.solid((90, 120, 255)), transparency=0.5, ior=1.)))
+    s.add(Aabb((-1., 3.5, -2.), (0.4, 0.1, 0.4), sdl_material(Texture.solid((255, 255, 200)), emissivity=1.)))
+    s.add(Aabb((1.2, 0.2, 3.), (0.3, 0.3, 0.3), sdl_material(Texture.solid((255, 160, 0)), emissivity=0.5)))
+    return s
+
+
+def reference_asset(name):
+    """Path of a file under the reference checkout, or None where it is absent (the GPU box)."""
+    p = os.path.join("/root/reference", name)
+    return p if os.path.exists(p) else None
