@@ -1,0 +1,196 @@
+"""Headline benchmark: Mrays/s (primary + secondary + shadow) and ms/frame on BASELINE config 4 --
+a 708x708-cell height field (1,002,528 triangles) with one glass sphere, 8 point lights with shadow rays,
+depth-4 reflection/refraction, 3840x2160 -- tile-sharded over N GPUs with a gather of the frame to rank 0.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one frame: every rank renders its interleaved 16x16 tiles (rt_render_shard), the compact tile buffers are
+gathered to rank 0 (RCCL) and scattered into the row-major frame (rt_detile).  The scene is resident in HBM before the
+timed region; the frame stays in HBM.  A ray is one Scene::cast_ray_once call of the reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, spec
+
+
+def cpu_leg(scene, vw, vh, seconds, cores, frame_rgb):
+    """The CPU oracle (a line-for-line f64 port of the reference path, one thread per core, dynamic chunks) on a
+    uniformly random pixel sample of the SAME frame, sized for about `seconds` of wall time.  Returns the timing,
+    the per-frame work counts scaled from the sample, and the GPU-vs-CPU parity on the sampled pixels."""
+    import oracle
+    from raytracer_amd.compare import image_metrics
+    total = vw * vh
+    rng = np.random.default_rng(12345)
+    pilot = rng.choice(total, size=min(2000, total), replace=False).astype(np.uint32)
+    t0 = time.perf_counter()
+    oracle.render(scene, cores, pixels=pilot, ids=False)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    n = int(min(total, max(len(pilot), len(pilot) * seconds / dt)))
+    px = rng.choice(total, size=n, replace=False).astype(np.uint32)
+    t0 = time.perf_counter()
+    rgb, _, st, oc = oracle.render(scene, cores, pixels=px, ids=False)
+    dt = time.perf_counter() - t0
+    scale = total / float(n)
+    parity = image_metrics(frame_rgb.reshape(-1, 3)[px], rgb) if frame_rgb is not None else None
+    return {
+        "seconds": dt, "pixels": n, "rays": int(st.rays), "mrays_s": st.rays / dt / 1e6, "scale": scale,
+        "bytes_closest": oc.algorithmic_bytes(0) * scale,
+        "bytes_shadow": oc.algorithmic_bytes(1) * scale,
+        "bytes_helper": oc.algorithmic_bytes(2) * scale,
+        "bytes_texels": 3.0 * (oc.texel_image + oc.texel_cubemap) * scale,
+        "counts": oc.as_dict(), "parity": parity, "would_panic": int(oc.would_panic),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--cells", type=int, default=708)
+    ap.add_argument("--lights", type=int, default=8)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import raytracer_amd as ra
+    from raytracer_amd import dist as rd
+    from raytracer_amd import scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    vw, vh = args.width, args.height
+    t0 = time.perf_counter()
+    scene = scenes.synthetic_terrain_scene(vw, vh, cells=args.cells, n_lights=args.lights)
+    t_build = time.perf_counter() - t0
+    ctx = ra.Context(local_rank)
+    t0 = time.perf_counter()
+    ctx.upload(scene)
+    t_upload = time.perf_counter() - t0
+    info = ra.desc_info(scene.flatten())
+    r = rd.ShardedRenderer(ctx, rank, world, device)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        r.render()
+    sync()
+    ms_trace = ms_shade = ms_resolve = ms_kernels = 0.0
+    launches = 0
+    st = None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st, frame = r.render()
+        ms_trace += st.ms_trace; ms_shade += st.ms_shade; ms_resolve += st.ms_resolve; ms_kernels += st.ms_render
+        launches += sum(1 for x in st.rays_per_level if x)
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    rays = torch.tensor([st.rays_primary, st.rays_reflect, st.rays_transmit, st.rays_shadow], dtype=torch.int64, device=device)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    rays = [int(x) for x in rays.cpu()]
+    elapsed = float(tmax.cpu()[0])
+    rays_frame = sum(rays)
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = rays_frame * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        frame_rgb = frame.cpu().numpy().reshape(vh, vw, 3)
+        cores = int(os.environ.get("OMP_NUM_THREADS") or min(os.cpu_count() or 1, 16))
+        # N == 1: the timed CPU baseline.  N > 1: only a short counting pass for the roofline numerator.
+        cpu = cpu_leg(scene, vw, vh, args.cpu_seconds if world == 1 else 3.0, cores, frame_rgb)
+
+        # Roofline of the dominant kernel (k_shade: light loop + shadow casts + child generation).  Its algorithmic
+        # bytes are those of the shadow casts, the refraction helper intersects and the texel fetches, counted under
+        # the reference's exhaustive semantics (32 B per BVH node test, 36 per triangle, 16/28/24 per sphere/plane/
+        # box, 3 per texel) on the sampled pixels and scaled to the frame; k_trace owns the closest-hit casts.
+        # With N ranks each launch handles 1/N of the frame.
+        shade_bytes_frame = cpu["bytes_shadow"] + cpu["bytes_helper"] + cpu["bytes_texels"]
+        trace_bytes_frame = cpu["bytes_closest"]
+        n_launch_frame = max(launches / max(args.steps, 1), 1.0)
+        kernels = {}
+        for name, bytes_frame, ms in (("k_shade", shade_bytes_frame, ms_shade), ("k_trace", trace_bytes_frame, ms_trace)):
+            avg_ms = ms / max(launches, 1)
+            bytes_launch = bytes_frame / world / n_launch_frame
+            gbs = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            kernels[name] = {"avg_launch_ms": avg_ms, "launches_per_frame": n_launch_frame, "bytes_per_launch": bytes_launch, "GB/s": gbs}
+        dom = "k_shade" if ms_shade >= ms_trace else "k_trace"
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("kernel") == dom and tj.get("n_gpus") == world and tj.get("workload_cells") == args.cells:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (primary+secondary)", "value": value, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"synthetic {info['n_tris']}-triangle height field ({args.cells}x{args.cells} cells) + 1 glass sphere + "
+                            f"{args.lights} point lights with shadows, {vw}x{vh}, max_ray_depth 4 (BASELINE config 4)",
+                "resolution": [vw, vh], "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "lights": args.lights,
+                "parallelism": f"image tiles 16x16 interleaved over {world} GPU(s), gather to rank 0",
+            },
+            "rays_per_frame": {"primary": rays[0], "reflect": rays[1], "transmit": rays[2], "shadow": rays[3], "total": rays_frame},
+            "ms_per_frame_kernels_rank0": ms_kernels / args.steps,
+            "ms_phase_rank0": {"trace": ms_trace / args.steps, "shade": ms_shade / args.steps, "resolve": ms_resolve / args.steps},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kernels[dom]["GB/s"] / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": kernels[dom]["avg_launch_ms"], "algorithmic_bytes_per_launch": kernels[dom]["bytes_per_launch"],
+                         "kernels": kernels},
+            "parity_vs_cpu_sample": cpu["parity"],
+            "setup_s": {"scene_build": t_build, "upload": t_upload}, "device_bytes": int(st.device_bytes),
+        }
+        if world == 1:
+            out["cpu_baseline"] = {
+                "value": cpu["mrays_s"], "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "sample": f"{cpu['pixels']} uniformly random pixels of the same frame ({cpu['rays']} rays) in {cpu['seconds']:.1f} s; "
+                          f"exhaustive reference traversal (no closest-hit pruning), {cores} threads",
+            }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,10 +18,20 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 class OrcCounts(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("node_tests", "tri_tests", "sphere_tests", "plane_tests", "box_tests",
-                                           "texel_image", "texel_cubemap", "would_panic")]
+                                           "texel_image", "texel_cubemap", "would_panic")] + [("by_ctx", (C.c_uint64 * 5) * 3)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "by_ctx"}
+        for ci, cname in enumerate(("closest", "shadow", "helper")):
+            d[cname] = dict(zip(("node", "tri", "sphere", "plane", "box"), [int(x) for x in self.by_ctx[ci]]))
+        return d
+
+    def algorithmic_bytes(self, ctx=None):
+        """32 B per BVH node test, 36 per triangle, 16 per sphere, 28 per plane, 24 per box (fp32 payload sizes),
+        for one cast context (0 closest, 1 shadow, 2 helper) or all of them"""
+        w = (32, 36, 16, 28, 24)
+        rows = range(3) if ctx is None else (ctx,)
+        return sum(int(self.by_ctx[c][k]) * w[k] for c in rows for k in range(5))
 
 
 def _stats_type():

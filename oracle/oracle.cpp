@@ -34,8 +34,11 @@ constexpr double EPSILON = 0.00000000001;  // scene.rs:13
 constexpr double METER = 2.;               // lighting/mod.rs:13
 
 /* ---- per-thread work counters (oracle extension, not in the reference) -- */
+enum { CTX_CLOSEST = 0, CTX_SHADOW = 1, CTX_HELPER = 2 };   // which kind of cast a primitive test belongs to
 struct Counts {
-    uint64_t node_tests = 0, tri_tests = 0, sphere_tests = 0, plane_tests = 0, box_tests = 0;
+    uint64_t node_tests = 0, tri_tests = 0, sphere_tests = 0, plane_tests = 0, box_tests = 0;   // all contexts
+    uint64_t by_ctx[3][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};             // [ctx][node,tri,sphere,plane,box]
+    int ctx = CTX_CLOSEST;
     uint64_t texel_image = 0, texel_cubemap = 0;
     uint64_t rays_primary = 0, rays_reflect = 0, rays_transmit = 0, rays_shadow = 0;
     uint64_t rays_per_level[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -43,6 +46,7 @@ struct Counts {
     void add(const Counts& o) {
         node_tests += o.node_tests; tri_tests += o.tri_tests; sphere_tests += o.sphere_tests;
         plane_tests += o.plane_tests; box_tests += o.box_tests;
+        for (int c = 0; c < 3; c++) for (int k = 0; k < 5; k++) by_ctx[c][k] += o.by_ctx[c][k];
         texel_image += o.texel_image; texel_cubemap += o.texel_cubemap;
         rays_primary += o.rays_primary; rays_reflect += o.rays_reflect;
         rays_transmit += o.rays_transmit; rays_shadow += o.rays_shadow;
@@ -52,6 +56,12 @@ struct Counts {
 };
 thread_local Counts* tl_counts = nullptr;
 #define COUNT(field) do { if (tl_counts) tl_counts->field++; } while (0)
+#define COUNT_TEST(field, k) do { if (tl_counts) { tl_counts->field++; tl_counts->by_ctx[tl_counts->ctx][k]++; } } while (0)
+struct CtxScope {   // switches the counting context for the duration of a cast
+    int saved = 0;
+    explicit CtxScope(int c) { if (tl_counts) { saved = tl_counts->ctx; tl_counts->ctx = c; } }
+    ~CtxScope() { if (tl_counts) tl_counts->ctx = saved; }
+};
 
 /* ---- math/vector.rs ------------------------------------------------------ */
 struct V3 { double x, y, z; };
@@ -175,7 +185,7 @@ struct Hit {
 
 /* sphere.rs:33-62 */
 bool sphere_intersect(const rt_sphere& s, const Ray& ray, Hit& h) {
-    COUNT(sphere_tests);
+    COUNT_TEST(sphere_tests, 2);
     V3 origin = v3(s.c[0], s.c[1], s.c[2]);
     double rad2 = s.r * s.r;
     V3 l = origin - ray.origin;
@@ -199,7 +209,7 @@ bool sphere_intersect(const rt_sphere& s, const Ray& ray, Hit& h) {
 
 /* plane.rs:49-79 */
 bool plane_intersect(const rt_plane& p, const Ray& ray, Hit& h) {
-    COUNT(plane_tests);
+    COUNT_TEST(plane_tests, 3);
     V3 origin = v3(p.p0[0], p.p0[1], p.p0[2]);
     V3 normal = v3(p.n[0], p.n[1], p.n[2]);
     double denom = dot(normal, ray.direction);
@@ -225,7 +235,7 @@ bool plane_intersect(const rt_plane& p, const Ray& ray, Hit& h) {
 
 /* aabb.rs:18-67 */
 bool box_intersect(V3 pos, V3 size, const Ray& ray, Hit& h) {
-    COUNT(box_tests);
+    COUNT_TEST(box_tests, 4);
     V3 ro = ray.origin - pos;
     V3 s = v3(-signum(ray.direction.x), -signum(ray.direction.y), -signum(ray.direction.z));
     V3 t1 = ray.m * (-ro + (s * size));
@@ -257,7 +267,7 @@ bool box_intersect(V3 pos, V3 size, const Ray& ray, Hit& h) {
 
 /* acceleration.rs:134-151 (centroid = (min+max)*0.5, :76) */
 bool aabb_bool(const rt_bvh_node& nd, const Ray& ray) {
-    COUNT(node_tests);
+    COUNT_TEST(node_tests, 0);
     V3 mn = v3(nd.min[0], nd.min[1], nd.min[2]);
     V3 mx = v3(nd.max[0], nd.max[1], nd.max[2]);
     V3 centroid = (mn + mx) * 0.5;
@@ -275,7 +285,7 @@ bool aabb_bool(const rt_bvh_node& nd, const Ray& ray) {
 /* mesh.rs:12-59 */
 struct TriIntersect { V3 p; double t; float u, v; };
 bool triangle_intersect(V3 v0, V3 v1, V3 v2, const Ray& ray, TriIntersect& out) {
-    COUNT(tri_tests);
+    COUNT_TEST(tri_tests, 1);
     V3 edge1 = v1 - v0;
     V3 edge2 = v2 - v0;
     V3 h = cross(ray.direction, edge2);
@@ -486,6 +496,7 @@ LightShading point_like(const Scene& sc, const rt_light& L, V3 position, const R
     Ray shadow_ray = ray_new(hit.vnear + hit.normal * EPSILON, lvec);
     uint32_t so; Hit sh;
     COUNT(rays_shadow);
+    CtxScope cs(CTX_SHADOW);
     if (cast_ray_once(sc, shadow_ray, so, sh)) {
         if (sh.near <= dist) { diffuse *= 0.; specular *= 0.; }
     }
@@ -505,6 +516,7 @@ LightShading light_shading(const Scene& sc, const rt_light& L, const Ray& ray, c
                 Ray shadow_ray = ray_new(hit.vnear + hit.normal * EPSILON, lvec);
                 uint32_t so; Hit sh;
                 COUNT(rays_shadow);
+                CtxScope cs(CTX_SHADOW);
                 if (cast_ray_once(sc, shadow_ray, so, sh)) {
                     diffuse *= L.shadow_coefficient;
                     specular *= L.shadow_coefficient;
@@ -592,10 +604,15 @@ Color trace_ray(const Scene& sc, const Ray& ray, uint32_t depth, Rng& rng, uint3
             if (!refraction_vec(ray, hit.normal, 1., ior, ref_vec)) {
                 COUNT(would_panic);                                               /* unwrap() :140 */
             } else {
-                Hit ref_hit;
-                if (object_intersect(sc, oi, ray_new(hit.vnear - ref_vec, ref_vec), ref_hit)) {
-                    Hit exit_hit;
-                    if (object_intersect(sc, oi, ray_new(ref_hit.vfar + ref_vec, -ref_vec), exit_hit)) {
+                Hit ref_hit, exit_hit;
+                bool ok1, ok2 = false;
+                {
+                    CtxScope cs(CTX_HELPER);
+                    ok1 = object_intersect(sc, oi, ray_new(hit.vnear - ref_vec, ref_vec), ref_hit);
+                    if (ok1) ok2 = object_intersect(sc, oi, ray_new(ref_hit.vfar + ref_vec, -ref_vec), exit_hit);
+                }
+                if (ok1) {
+                    if (ok2) {
                         V3 exit_ref_vec;
                         if (refraction_vec(ray_new(ref_hit.vfar + ref_vec * EPSILON, ref_vec), -exit_hit.normal, ior, 1., exit_ref_vec)) {
                             COUNT(rays_transmit);
@@ -661,6 +678,7 @@ void fill_stats(const Counts& c, rt_stats* s, orc_counts* oc) {
         oc->plane_tests = c.plane_tests; oc->box_tests = c.box_tests;
         oc->texel_image = c.texel_image; oc->texel_cubemap = c.texel_cubemap;
         oc->would_panic = c.would_panic;
+        for (int x = 0; x < 3; x++) for (int k = 0; k < 5; k++) oc->by_ctx[x][k] = c.by_ctx[x][k];
     }
 }
 

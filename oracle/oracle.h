@@ -19,6 +19,10 @@ typedef struct orc_counts {
     uint64_t node_tests, tri_tests, sphere_tests, plane_tests, box_tests;
     uint64_t texel_image, texel_cubemap;
     uint64_t would_panic;   /* places where the reference would panic */
+    /* the same tests split by the cast they belong to: [0] closest-hit casts of trace_ray (scene.rs:97),
+     * [1] shadow casts (sun.rs:89, point.rs:91), [2] the same-object helper intersects of the refraction
+     * branch (scene.rs:143-147); columns: node, triangle, sphere, plane, box */
+    uint64_t by_ctx[3][5];
 } orc_counts;
 
 int rt_cpu_render(const rt_scene_desc* d, int n_threads, uint8_t* rgb_out, uint32_t* prim_id_out,

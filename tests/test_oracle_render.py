@@ -1,0 +1,87 @@
+"""Whole-frame properties of the CPU oracle (reference semantics), independent of any GPU."""
+import numpy as np
+import pytest
+
+import oracle
+import raytracer_amd as ra
+from raytracer_amd import scenes
+from raytracer_amd.compare import ray_counts
+
+
+def test_pixel_subset_equals_full_render():
+    s = scenes.small_mixed_scene(64, 48, cells=8)
+    rgb, ids, st, oc = oracle.render(s, 0)
+    px = np.random.default_rng(0).choice(64 * 48, 300, replace=False).astype(np.uint32)
+    r2, i2, st2, _ = oracle.render(s, 0, pixels=px)
+    assert np.array_equal(r2, rgb.reshape(-1, 3)[px]) and np.array_equal(i2, ids.reshape(-1, 2)[px])
+    assert st2.rays_primary == 300
+
+
+def test_thread_count_does_not_change_the_frame():
+    s = scenes.refraction_scene(96, 54)
+    a = oracle.render(s, 1)
+    b = oracle.render(s, 5)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert ray_counts(a[2]) == ray_counts(b[2]) and a[3].as_dict() == b[3].as_dict()
+
+
+def test_ray_accounting():
+    s = scenes.refraction_scene(96, 54)
+    rgb, ids, st, oc = oracle.render(s, 0)
+    assert st.rays_primary == 96 * 54 == st.rays_per_level[0]
+    # every trace_ray call below depth 0 is a reflection or a transmission ray (scene.rs:134,154,169,190)
+    assert sum(st.rays_per_level[1:]) == st.rays_reflect + st.rays_transmit
+    assert st.rays_per_level[5] == 0                                        # max_ray_depth 4 (scene.rs:28)
+    # one sun with shadows: one shadow ray per shaded hit (sun.rs:87-89); misses cast none
+    hits_total = sum(st.rays_per_level) - 0
+    assert 0 < st.rays_shadow <= hits_total
+    # the linear scan tests every object for every cast (scene.rs:61-66): 3 spheres, 1 plane
+    casts = st.rays
+    assert oc.plane_tests == casts
+    assert oc.sphere_tests >= 3 * casts                                     # + the same-object helper intersects (scene.rs:143-147)
+    assert oc.would_panic == 0
+
+
+def test_ids_agree_with_geometry():
+    s = scenes.loop_scene(200, 150)
+    rgb, ids, st, oc = oracle.render(s, 0)
+    miss = ids[..., 0] == 0xFFFFFFFF
+    assert miss.any() and (~miss).any()
+    assert (ids[..., 1] == 0xFFFFFFFF).all()                                # no meshes: no triangle ids
+    assert set(np.unique(ids[..., 0][~miss])) <= set(range(16))
+    # Normal skybox: colour = from_normal(direction); the centre pixel of an empty view looks down -z
+    e = ra.Scene()
+    e.set_camera(ra.Camera(vw=8, vh=8))
+    assert list(oracle.render(e, 1)[0][4, 4]) == [127, 127, 0]
+
+
+def test_max_depth_zero_and_no_lights():
+    s = scenes.refraction_scene(64, 36)
+    s.set_options(max_ray_depth=0)
+    rgb, ids, st, oc = oracle.render(s, 0)
+    assert st.rays_reflect == 0 and st.rays_transmit == 0
+    e = ra.Scene()
+    e.set_camera(ra.Camera(vw=32, vh=32))
+    e.skybox_solid((1, 2, 3))
+    e.add(ra.Sphere((0, 0, -3), 1.0))
+    rgb, ids, st, oc = oracle.render(e, 0)
+    assert st.rays_shadow == 0
+    assert list(rgb[16, 16]) == [40, 40, 40]                                # white * ambient 40/255 (scene.rs:110,122)
+    assert list(rgb[0, 0]) == [1, 2, 3]
+
+
+def test_area_light_runs_and_is_repeatable():
+    s = scenes.cornell_scene(48, 48)
+    a = oracle.render(s, 3)
+    b = oracle.render(s, 1)
+    assert np.array_equal(a[0], b[0])                                       # the seeded stand-in RNG is per pixel
+    assert a[2].rays_shadow > 48 * 48                                       # 64 samples per hit (cornell.sdl:29)
+
+
+def test_emissive_surface_ignores_lighting():
+    e = ra.Scene()
+    e.set_camera(ra.Camera(vw=16, vh=16))
+    e.add(ra.Aabb((0, 0, -3), (5, 5, 0.1), ra.Material(ra.Texture.solid((10, 200, 30)), emissivity=1.0)))
+    e.add_light(ra.Sun())
+    rgb, ids, st, oc = oracle.render(e, 1)
+    assert (rgb == np.array([10, 200, 30], dtype=np.uint8)).all() and st.rays_shadow == 0   # scene.rs:105-107
