@@ -33,7 +33,7 @@ def cpu_leg(scene, vw, vh, seconds, cores, frame_rgb):
     from raytracer_amd.compare import image_metrics
     total = vw * vh
     rng = np.random.default_rng(12345)
-    pilot = rng.choice(total, size=min(2000, total), replace=False).astype(np.uint32)
+    pilot = rng.choice(total, size=min(20000, total), replace=False).astype(np.uint32)
     t0 = time.perf_counter()
     oracle.render(scene, cores, pixels=pilot, ids=False)
     dt = max(time.perf_counter() - t0, 1e-4)
@@ -44,6 +44,8 @@ def cpu_leg(scene, vw, vh, seconds, cores, frame_rgb):
     dt = time.perf_counter() - t0
     scale = total / float(n)
     parity = image_metrics(frame_rgb.reshape(-1, 3)[px], rgb) if frame_rgb is not None else None
+    if parity and parity["psnr"] == float("inf"):
+        parity["psnr"] = None   # identical: PSNR is unbounded (JSON has no infinity)
     return {
         "seconds": dt, "pixels": n, "rays": int(st.rays), "mrays_s": st.rays / dt / 1e6, "scale": scale,
         "bytes_closest": oc.algorithmic_bytes(0) * scale,
@@ -107,14 +109,15 @@ def main():
     for _ in range(args.warmup):
         r.render()
     sync()
-    ms_trace = ms_shade = ms_resolve = ms_kernels = 0.0
-    launches = 0
+    ms_trace = ms_shadow = ms_shade = ms_resolve = ms_kernels = 0.0
+    launches = {"k_trace": 0, "k_shadow": 0, "k_shade": 0}
     st = None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         st, frame = r.render()
-        ms_trace += st.ms_trace; ms_shade += st.ms_shade; ms_resolve += st.ms_resolve; ms_kernels += st.ms_render
-        launches += sum(1 for x in st.rays_per_level if x)
+        ms_trace += st.ms_trace; ms_shadow += st.ms_shadow; ms_shade += st.ms_shade; ms_resolve += st.ms_resolve
+        ms_kernels += st.ms_render
+        launches["k_trace"] += st.launches_trace; launches["k_shadow"] += st.launches_shadow; launches["k_shade"] += st.launches_shade
     sync()
     elapsed = time.perf_counter() - t0
 
@@ -135,21 +138,22 @@ def main():
         # N == 1: the timed CPU baseline.  N > 1: only a short counting pass for the roofline numerator.
         cpu = cpu_leg(scene, vw, vh, args.cpu_seconds if world == 1 else 3.0, cores, frame_rgb)
 
-        # Roofline of the dominant kernel (k_shade: light loop + shadow casts + child generation).  Its algorithmic
-        # bytes are those of the shadow casts, the refraction helper intersects and the texel fetches, counted under
-        # the reference's exhaustive semantics (32 B per BVH node test, 36 per triangle, 16/28/24 per sphere/plane/
-        # box, 3 per texel) on the sampled pixels and scaled to the frame; k_trace owns the closest-hit casts.
-        # With N ranks each launch handles 1/N of the frame.
-        shade_bytes_frame = cpu["bytes_shadow"] + cpu["bytes_helper"] + cpu["bytes_texels"]
-        trace_bytes_frame = cpu["bytes_closest"]
-        n_launch_frame = max(launches / max(args.steps, 1), 1.0)
+        # Roofline of the dominant kernel.  Algorithmic bytes are counted under the reference's exhaustive semantics
+        # (32 B per BVH node test, 36 per triangle, 16/28/24 per sphere/plane/box, 3 per texel) on the sampled pixels
+        # and scaled to the frame: k_trace owns the closest-hit casts, k_shadow the shadow casts, k_shade the
+        # refraction helper intersects and the texel fetches.  With N ranks each launch handles 1/N of the frame;
+        # a frame launches each kernel once per trace_ray depth that has rays.
+        per_kernel = {"k_trace": (cpu["bytes_closest"], ms_trace), "k_shadow": (cpu["bytes_shadow"], ms_shadow),
+                      "k_shade": (cpu["bytes_helper"] + cpu["bytes_texels"], ms_shade)}
         kernels = {}
-        for name, bytes_frame, ms in (("k_shade", shade_bytes_frame, ms_shade), ("k_trace", trace_bytes_frame, ms_trace)):
-            avg_ms = ms / max(launches, 1)
-            bytes_launch = bytes_frame / world / n_launch_frame
+        for name, (bytes_frame, ms) in per_kernel.items():
+            n_l = max(launches[name], 1)
+            avg_ms = ms / n_l
+            bytes_launch = bytes_frame / world / (n_l / max(args.steps, 1))
             gbs = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            kernels[name] = {"avg_launch_ms": avg_ms, "launches_per_frame": n_launch_frame, "bytes_per_launch": bytes_launch, "GB/s": gbs}
-        dom = "k_shade" if ms_shade >= ms_trace else "k_trace"
+            kernels[name] = {"avg_launch_ms": avg_ms, "launches_per_frame": n_l / max(args.steps, 1), "bytes_per_launch": bytes_launch,
+                             "GB/s": gbs, "ms_per_frame": ms / max(args.steps, 1)}
+        dom = max(per_kernel, key=lambda k: per_kernel[k][1])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -171,7 +175,8 @@ def main():
             },
             "rays_per_frame": {"primary": rays[0], "reflect": rays[1], "transmit": rays[2], "shadow": rays[3], "total": rays_frame},
             "ms_per_frame_kernels_rank0": ms_kernels / args.steps,
-            "ms_phase_rank0": {"trace": ms_trace / args.steps, "shade": ms_shade / args.steps, "resolve": ms_resolve / args.steps},
+            "ms_phase_rank0": {"trace": ms_trace / args.steps, "shadow": ms_shadow / args.steps, "shade": ms_shade / args.steps,
+                               "resolve": ms_resolve / args.steps},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dom]["GB/s"] / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": kernels[dom]["avg_launch_ms"], "algorithmic_bytes_per_launch": kernels[dom]["bytes_per_launch"],

@@ -163,8 +163,14 @@ typedef struct rt_stats {
     double   ms_upload;           /* last rt_scene_upload                   */
     double   ms_render;           /* kernels of the last frame (HIP events) */
     double   ms_total;            /* render + copy-out wall time            */
-    double   ms_trace, ms_shade, ms_resolve;   /* per-phase kernel time     */
+    double   ms_trace, ms_shadow, ms_shade, ms_resolve;   /* per-phase kernel time, summed over depths */
     uint64_t device_bytes;        /* device memory held by the context      */
+    /* Work the traversal kernels really did: inner BVH nodes visited (two box
+     * tests each) and triangles tested.  Only counted when the context was
+     * created with RTGPU_COUNT_VISITS=1 in the environment (instrumented kernel
+     * variants, slower); 0 otherwise. */
+    uint64_t nodes_visited, tris_tested;
+    uint32_t launches_trace, launches_shadow, launches_shade, _pad;   /* kernel launches of the last frame */
 } rt_stats;
 
 /* result of one probe ray (rt_cast_rays): the fields of object/mod.rs:18-36

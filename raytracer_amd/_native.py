@@ -26,8 +26,10 @@ class RtStats(C.Structure):
         ("rays_transmit", C.c_uint64), ("rays_shadow", C.c_uint64),
         ("rays_per_level", C.c_uint64 * 8),
         ("ms_upload", C.c_double), ("ms_render", C.c_double), ("ms_total", C.c_double),
-        ("ms_trace", C.c_double), ("ms_shade", C.c_double), ("ms_resolve", C.c_double),
+        ("ms_trace", C.c_double), ("ms_shadow", C.c_double), ("ms_shade", C.c_double), ("ms_resolve", C.c_double),
         ("device_bytes", C.c_uint64),
+        ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
+        ("launches_trace", C.c_uint32), ("launches_shadow", C.c_uint32), ("launches_shade", C.c_uint32), ("_pad", C.c_uint32),
     ]
 
     @property

@@ -9,6 +9,11 @@
 
 #define DEV __device__ __forceinline__
 
+// Pointers read out of device structs are generic to the compiler; casting them to the global address space
+// makes the loads global_load (one counter to wait on) instead of flat_load.
+#define RT_GLOBAL __attribute__((address_space(1)))
+template <typename T> DEV const RT_GLOBAL T* gptr(const T* p) { return (const RT_GLOBAL T*)p; }
+
 // ---------------------------------------------------------------- vector.rs
 DEV D3 d3(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
 DEV D3 operator+(D3 a, D3 b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -22,7 +27,7 @@ DEV double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }        
 DEV D3 cross(D3 a, D3 b) { return d3(a.y * b.z - a.z * b.y, -a.x * b.z + a.z * b.x, a.x * b.y - a.y * b.x); }  // :65-71
 DEV double magnitude(D3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }                 // :74-76
 DEV D3 normalize(D3 a) { return a / magnitude(a); }                                            // :79-81
-DEV D3 ld3(const double* p) { return d3(p[0], p[1], p[2]); }
+template <typename P> DEV D3 ld3(P p) { return d3(p[0], p[1], p[2]); }
 
 // Rust f64::signum: NaN -> NaN, otherwise +-1 with the sign of x (signum(+-0) = +-1)
 DEV double signum(double x) { return x != x ? x : copysign(1.0, x); }
@@ -59,18 +64,21 @@ DEV D3 to_d3(uint32_t c) { return d3((double)(c & 255u) / 255., (double)((c >> 8
 // ---------------------------------------------------------------- ray.rs
 struct Ray {
     D3 o, d, m;          // origin, direction, 1/direction (ray.rs:17-23)
-    uint32_t fx, fy, fz; // sign-bit masks that turn `size` into `s * size`, s = -signum(d)
+    // f32 view for BVH culling: origin as an unevaluated sum hi + lo (so that no origin
+    // rounding enters the slab distances), 1/direction rounded to f32, direction signs
+    float ohx, ohy, ohz, olx, oly, olz, mfx, mfy, mfz;
+    bool nx, ny, nz;     // sign bit of the direction: the near slab bound is max when set (s = -signum(d), aabb.rs:21-25)
 };
 DEV Ray ray_new(D3 o, D3 d) {
     Ray r; r.o = o; r.d = d; r.m = d3(1. / d.x, 1. / d.y, 1. / d.z);
-    // s = -signum(d) is -1 when d's sign bit is clear: flip the sign of size then
-    r.fx = (~(uint32_t)__double2hiint(d.x)) & 0x80000000u;
-    r.fy = (~(uint32_t)__double2hiint(d.y)) & 0x80000000u;
-    r.fz = (~(uint32_t)__double2hiint(d.z)) & 0x80000000u;
+    r.ohx = (float)o.x; r.olx = (float)(o.x - (double)r.ohx);
+    r.ohy = (float)o.y; r.oly = (float)(o.y - (double)r.ohy);
+    r.ohz = (float)o.z; r.olz = (float)(o.z - (double)r.ohz);
+    r.mfx = (float)r.m.x; r.mfy = (float)r.m.y; r.mfz = (float)r.m.z;
+    r.nx = __double2hiint(d.x) < 0; r.ny = __double2hiint(d.y) < 0; r.nz = __double2hiint(d.z) < 0;
     return r;
 }
 DEV D3 along(const Ray& r, double t) { return r.o + r.d * t; }                                 // ray.rs:26-28
-DEV double flipsign(double v, uint32_t mask) { return __hiloint2double(__double2hiint(v) ^ (int)mask, __double2loint(v)); }
 
 // math/mod.rs:48-63
 DEV bool refraction_vec(D3 dir, D3 normal, double from_ior, double to_ior, D3& out) {
@@ -87,7 +95,7 @@ DEV bool refraction_vec(D3 dir, D3 normal, double from_ior, double to_ior, D3& o
 struct Hit { D3 normal; double near; D3 vnear; double far; D3 vfar; float u, v; uint32_t prim; };
 
 // sphere.rs:33-62.  `near_only`: just the hit test and `near`.
-DEV bool sphere_near(const double* s, const Ray& ray, double& near) {
+template <typename P> DEV bool sphere_near(P s, const Ray& ray, double& near) {
     D3 origin = ld3(s);
     double rad2 = s[3] * s[3];
     D3 l = origin - ray.o;
@@ -99,7 +107,7 @@ DEV bool sphere_near(const double* s, const Ray& ray, double& near) {
     near = t2 - t3;
     return true;
 }
-DEV bool sphere_intersect(const double* s, const Ray& ray, Hit& h) {
+template <typename P> DEV bool sphere_intersect(P s, const Ray& ray, Hit& h) {
     D3 origin = ld3(s);
     double rad2 = s[3] * s[3];
     D3 l = origin - ray.o;
@@ -122,7 +130,7 @@ DEV bool sphere_intersect(const double* s, const Ray& ray, Hit& h) {
 }
 
 // plane.rs:49-79
-DEV bool plane_near(const double* p, const Ray& ray, double& near) {
+template <typename P> DEV bool plane_near(P p, const Ray& ray, double& near) {
     D3 origin = ld3(p), normal = ld3(p + 3);
     double denom = dot(normal, ray.d);
     if (fabs(denom) > RT_EPSILON) {
@@ -131,7 +139,7 @@ DEV bool plane_near(const double* p, const Ray& ray, double& near) {
     }
     return false;
 }
-DEV bool plane_intersect(const double* p, const Ray& ray, Hit& h) {
+template <typename P> DEV bool plane_intersect(P p, const Ray& ray, Hit& h) {
     D3 origin = ld3(p), normal = ld3(p + 3);
     float uv_wrap = (float)p[6];
     double denom = dot(normal, ray.d);
@@ -162,7 +170,7 @@ DEV bool box_slabs(D3 pos, D3 size, const Ray& ray, D3& s, D3& t1, double& tn, d
     tf = fmin(fmin(t2.x, t2.y), t2.z);
     return !(tn > tf || tf < 0.);
 }
-DEV bool box_near(const double* b, const Ray& ray, double& near) {
+template <typename P> DEV bool box_near(P b, const Ray& ray, double& near) {
     D3 s, t1; double tf;
     return box_slabs(ld3(b), ld3(b + 3), ray, s, t1, near, tf);
 }
@@ -193,22 +201,31 @@ DEV bool box_intersect(D3 pos, D3 size, const Ray& ray, Hit& h) {
 }
 
 // ---------------------------------------------------------------- mesh BVH
-// acceleration.rs:134-151 on a (centre, half size) box.  s*size is formed by
-// flipping the sign bit (multiplying by +-1 is exact, so the values are those
-// of the reference's `s * size`).
-DEV bool node_box(const double* c, const double* hs, const Ray& ray, double& tn) {
-    double nx = c[0] - ray.o.x, ny = c[1] - ray.o.y, nz = c[2] - ray.o.z;
-    double sx = flipsign(hs[0], ray.fx), sy = flipsign(hs[1], ray.fy), sz = flipsign(hs[2], ray.fz);
-    double t1x = ray.m.x * (nx + sx), t1y = ray.m.y * (ny + sy), t1z = ray.m.z * (nz + sz);
-    double t2x = ray.m.x * (nx - sx), t2y = ray.m.y * (ny - sy), t2z = ray.m.z * (nz - sz);
-    tn = fmax(fmax(t1x, t1y), t1z);
-    double tf = fmin(fmin(t2x, t2y), t2z);
-    return !(tn > tf || tf < 0.);
+// The slab test of acceleration.rs:134-151 in f32 on an outward-rounded box, made conservative: the entry
+// distance is pushed down and the exit distance up by 2^-20 relative, which covers the rounding of the two
+// subtractions, of 1/direction and of the product (<= 6 * 2^-24).  NaN slabs (0 * inf) are ignored by
+// fmaxf/fminf exactly as f64::max/min ignore them in the reference.
+#define RT_CULL_SLACK 9.5367431640625e-07f
+template <typename FP>
+DEV bool node_box(FP bmin, FP bmax, const Ray& ray, float& tn_out) {
+    const float ax = ray.nx ? bmax[0] : bmin[0], bx = ray.nx ? bmin[0] : bmax[0];
+    const float ay = ray.ny ? bmax[1] : bmin[1], by = ray.ny ? bmin[1] : bmax[1];
+    const float az = ray.nz ? bmax[2] : bmin[2], bz = ray.nz ? bmin[2] : bmax[2];
+    const float t1x = ((ax - ray.ohx) - ray.olx) * ray.mfx, t2x = ((bx - ray.ohx) - ray.olx) * ray.mfx;
+    const float t1y = ((ay - ray.ohy) - ray.oly) * ray.mfy, t2y = ((by - ray.ohy) - ray.oly) * ray.mfy;
+    const float t1z = ((az - ray.ohz) - ray.olz) * ray.mfz, t2z = ((bz - ray.ohz) - ray.olz) * ray.mfz;
+    float tn = fmaxf(fmaxf(t1x, t1y), t1z);
+    float tf = fminf(fminf(t2x, t2y), t2z);
+    tn = tn - fabsf(tn) * RT_CULL_SLACK;
+    tf = tf + fabsf(tf) * RT_CULL_SLACK;
+    tn_out = tn;
+    return !(tn > tf || tf < 0.f);
 }
 
 // mesh.rs:25-59 with the edges precomputed
-DEV bool tri_test(const DTri* T, const Ray& ray, double& t_out, float& u_out, float& v_out) {
-    D3 v0 = ld3(T->v0), edge1 = ld3(T->e1), edge2 = ld3(T->e2);
+template <typename TP>
+DEV bool tri_test(TP T, const Ray& ray, double& t_out, float& u_out, float& v_out) {
+    D3 v0 = d3(T->v0[0], T->v0[1], T->v0[2]), edge1 = d3(T->e1[0], T->e1[1], T->e1[2]), edge2 = d3(T->e2[0], T->e2[1], T->e2[2]);
     D3 h = cross(ray.d, edge2);
     double a = dot(edge1, h);
     if (a > -RT_EPSILON && a < RT_EPSILON) return false;
@@ -226,6 +243,35 @@ DEV bool tri_test(const DTri* T, const Ray& ray, double& t_out, float& u_out, fl
 
 struct MeshHit { double t0, t1; uint32_t r0; float u, v; uint32_t n; };   // n = hits kept (0, 1, 2)
 
+// Per-lane traversal context: the lane's stack column in LDS, and the work the traversal really did
+// (inner-node visits = two box tests each, triangle tests); only the instrumented kernel variants store the
+// counts, elsewhere the increments are dead code.
+struct Visits { uint32_t nodes, tris; };
+
+// Traversal stack: (node reference, entry distance) pairs.  The first RT_LDS_STACK entries of every lane live
+// in LDS, laid out [entry][lane] so that a wave's push or pop touches consecutive 8-byte words (no bank
+// conflicts); deeper entries spill to private memory.
+#define RT_BLOCK_DIM 256
+__shared__ uint2 rt_lds_stack[RT_LDS_STACK * RT_BLOCK_DIM];
+// push/pop on plain locals (sp, spill): kept out of any struct so that the stack pointer stays in a register.
+// The spill array is volatile so that the compiler keeps its (cold) accesses apart from the LDS ones instead
+// of folding both into one flat access through a selected generic pointer.
+#define RT_STACK_PUSH(ref_, tn_)                                                                          \
+    do {                                                                                                  \
+        if (sp < RT_LDS_STACK) rt_lds_stack[sp * RT_BLOCK_DIM + threadIdx.x] = make_uint2((ref_), __float_as_uint(tn_)); \
+        else spill[sp - RT_LDS_STACK] = (unsigned long long)(ref_) | ((unsigned long long)__float_as_uint(tn_) << 32);   \
+        ++sp;                                                                                             \
+    } while (0)
+#define RT_STACK_POP(out_)                                                                                \
+    do {                                                                                                  \
+        --sp;                                                                                             \
+        if (sp < RT_LDS_STACK) (out_) = rt_lds_stack[sp * RT_BLOCK_DIM + threadIdx.x];                    \
+        else { const unsigned long long w_ = spill[sp - RT_LDS_STACK]; (out_) = make_uint2((uint32_t)w_, (uint32_t)(w_ >> 32)); } \
+    } while (0)
+
+typedef const RT_GLOBAL DNode* GNodePtr;
+typedef const RT_GLOBAL DTri* GTriPtr;
+
 enum { TRAV_CLOSEST = 0, TRAV_TWO = 1, TRAV_ANY = 2 };
 
 // The reference gathers every triangle of every leaf whose chain of boxes the
@@ -238,33 +284,41 @@ enum { TRAV_CLOSEST = 0, TRAV_TWO = 1, TRAV_ANY = 2 };
 //   TRAV_TWO:     nearest and second nearest (Hit::far, mesh.rs:411-423).
 //   TRAV_ANY:     true as soon as one hit has t <= bound.
 template <int MODE>
-__device__ bool mesh_traverse(const DMesh& M, const Ray& ray, double bound, MeshHit& mh) {
+__device__ bool mesh_traverse(const DMesh& M, const Ray& ray, double bound, MeshHit& mh, Visits& vc) {
     mh.n = 0; mh.t0 = bound; mh.t1 = bound; mh.r0 = 0;   // r0 = 0: a hit AT an outside bound never wins the tie
-    double tn_root;
-    if (!node_box(M.root_c, M.root_h, ray, tn_root)) return false;
+    float tn_root;
+    if (!node_box(M.root_min, M.root_max, ray, tn_root)) return false;
 
-    uint32_t stack_ref[RT_MAX_STACK];
-    float stack_tn[RT_MAX_STACK];   // entry distance, rounded down: a skip never drops a box that could matter
     int sp = 0;
+    volatile unsigned long long spill[RT_MAX_STACK - RT_LDS_STACK];
+    const GNodePtr nodes = gptr(M.nodes);
+    const GTriPtr tris = gptr(M.tris);
     const uint32_t POP = 0xFFFFFFFFu;
     uint32_t cur = M.root_ref;
+    // boxes entered beyond `limit` cannot hold the answer; kept in f32, rounded up so that the skip stays safe
+    float limit = __double2float_ru(bound);
     while (true) {
         if (cur & RT_LEAF_BIT) {
             uint32_t rank = cur & ~RT_LEAF_BIT;
             while (true) {
-                const DTri* T = &M.tris[rank];
+                const GTriPtr T = &tris[rank];
                 const uint32_t last = T->last;
                 double t; float u, v;
+                vc.tris++;
                 if (tri_test(T, ray, t, u, v)) {
                     if (MODE == TRAV_ANY) {
                         if (t <= bound) return true;
                     } else if (MODE == TRAV_CLOSEST) {
-                        if (t < mh.t0 || (t == mh.t0 && rank < mh.r0)) { mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v; mh.n = 1; }
+                        if (t < mh.t0 || (t == mh.t0 && rank < mh.r0)) {
+                            mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v; mh.n = 1;
+                            limit = __double2float_ru(t);
+                        }
                     } else {
                         if (mh.n == 0 || t < mh.t0 || (t == mh.t0 && rank < mh.r0)) {
                             if (mh.n >= 1) { mh.t1 = mh.t0; mh.n = 2; } else mh.n = 1;
                             mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v;
                         } else if (mh.n == 1 || t < mh.t1) { mh.t1 = t; mh.n = 2; }
+                        if (mh.n == 2) limit = __double2float_ru(mh.t1);
                     }
                 }
                 if (last) break;
@@ -272,30 +326,28 @@ __device__ bool mesh_traverse(const DMesh& M, const Ray& ray, double bound, Mesh
             }
             cur = POP;
         } else {
-            const DNode* nd = &M.nodes[cur];
-            double tl, tr;
-            bool hl = node_box(nd->lc, nd->lh, ray, tl);
-            bool hr = node_box(nd->rc, nd->rh, ray, tr);
-            const double limit = (MODE == TRAV_TWO) ? (mh.n == 2 ? mh.t1 : INFINITY) : mh.t0;
+            const GNodePtr nd = &nodes[cur];
+            float tl, tr;
+            vc.nodes++;
+            bool hl = node_box(nd->lmin, nd->lmax, ray, tl);
+            bool hr = node_box(nd->rmin, nd->rmax, ray, tr);
             hl = hl && !(tl > limit);
             hr = hr && !(tr > limit);
             const uint32_t lref = nd->lref, rref = nd->rref;
             if (hl && hr) {
                 // nearer first; equal entry distances keep a before b (the reference's order)
                 const bool left_first = !(tr < tl);
-                stack_ref[sp] = left_first ? rref : lref;
-                stack_tn[sp] = __double2float_rd(left_first ? tr : tl);
-                ++sp;
+                RT_STACK_PUSH(left_first ? rref : lref, left_first ? tr : tl);
                 cur = left_first ? lref : rref;
             } else if (hl) cur = lref;
             else if (hr) cur = rref;
             else cur = POP;
         }
         if (cur == POP) {
-            const double limit = (MODE == TRAV_TWO) ? (mh.n == 2 ? mh.t1 : INFINITY) : mh.t0;
             while (sp > 0) {
-                --sp;
-                if (!((double)stack_tn[sp] > limit)) { cur = stack_ref[sp]; break; }
+                uint2 e;
+                RT_STACK_POP(e);
+                if (!(__uint_as_float(e.y) > limit)) { cur = e.x; break; }
             }
             if (cur == POP) break;
         }
@@ -306,19 +358,20 @@ __device__ bool mesh_traverse(const DMesh& M, const Ray& ray, double bound, Mesh
 // mesh.rs:348-439 from a traversal result (nearest triangle, its barycentrics,
 // second-nearest t)
 DEV void mesh_hit_fill(const DMesh& M, const Ray& ray, uint32_t rank, double t0, double t1, float bu, float bv, Hit& h) {
-    uint32_t tri = M.tris[rank].orig;
-    const uint32_t* n = &M.tri_nrm[3 * tri];
+    const uint32_t tri = gptr(M.tris)[rank].orig;
+    const RT_GLOBAL uint32_t* n = gptr(M.tri_nrm) + 3 * (size_t)tri;
+    const RT_GLOBAL double* nrm = gptr(M.normals);
     {   // triangle_intersect_normal, mesh.rs:79-89 (f32 weights, widened)
         float u = 1.f - bu - bv, v = bu, w = bv;
-        h.normal = ld3(&M.normals[3 * n[0]]) * (double)u + ld3(&M.normals[3 * n[1]]) * (double)v + ld3(&M.normals[3 * n[2]]) * (double)w;
+        h.normal = ld3(nrm + 3 * (size_t)n[0]) * (double)u + ld3(nrm + 3 * (size_t)n[1]) * (double)v + ld3(nrm + 3 * (size_t)n[2]) * (double)w;
     }
     h.near = t0; h.vnear = along(ray, t0);
     h.far = t1; h.vfar = along(ray, t1);
     if (M.tri_uv != nullptr && M.n_texcoords != 0) {   // triangle_intersect_uvs, mesh.rs:61-77
-        const uint32_t* c = &M.tri_uv[3 * tri];
-        const float* a = &M.texcoords[2 * c[0]];
-        const float* b = &M.texcoords[2 * c[1]];
-        const float* cc = &M.texcoords[2 * c[2]];
+        const RT_GLOBAL uint32_t* c = gptr(M.tri_uv) + 3 * (size_t)tri;
+        const RT_GLOBAL float* a = gptr(M.texcoords) + 2 * (size_t)c[0];
+        const RT_GLOBAL float* b = gptr(M.texcoords) + 2 * (size_t)c[1];
+        const RT_GLOBAL float* cc = gptr(M.texcoords) + 2 * (size_t)c[2];
         float iu = bu, iv = bv, iw = 1.f - bu - bv;
         float uu = a[0] * iw + b[0] * iu + cc[0] * iv;
         float vv = a[1] * iw + b[1] * iu + cc[1] * iv;
@@ -329,22 +382,23 @@ DEV void mesh_hit_fill(const DMesh& M, const Ray& ray, uint32_t rank, double t0,
 }
 
 // Mesh::intersect as a whole (used for the refraction helper rays, scene.rs:143-147)
-__device__ bool mesh_intersect(const DMesh& M, const Ray& ray, Hit& h) {
+__device__ bool mesh_intersect(const DMesh& M, const Ray& ray, Hit& h, Visits& vc) {
     MeshHit mh;
-    if (!mesh_traverse<TRAV_TWO>(M, ray, INFINITY, mh)) return false;
+    if (!mesh_traverse<TRAV_TWO>(M, ray, INFINITY, mh, vc)) return false;
     mesh_hit_fill(M, ray, mh.r0, mh.t0, mh.n >= 2 ? mh.t1 : mh.t0, mh.u, mh.v, h);
     return true;
 }
 
 // ---------------------------------------------------------------- scene casts
 // object.intersect(ray) for object oi (object/mod.rs:61-64)
-__device__ bool object_intersect(const DScene& S, uint32_t oi, const Ray& ray, Hit& h) {
-    const DObject o = S.objects[oi];
-    switch (o.kind) {
-        case 0: return sphere_intersect(&S.spheres[4 * o.payload], ray, h);
-        case 1: return plane_intersect(&S.planes[8 * o.payload], ray, h);
-        case 2: return box_intersect(ld3(&S.boxes[6 * o.payload]), ld3(&S.boxes[6 * o.payload + 3]), ray, h);
-        default: return mesh_intersect(S.meshes[o.payload], ray, h);
+__device__ bool object_intersect(const DScene& S, uint32_t oi, const Ray& ray, Hit& h, Visits& vc) {
+    const RT_GLOBAL DObject* op = gptr(S.objects) + oi;
+    const uint32_t kind = op->kind, payload = op->payload;
+    switch (kind) {
+        case 0: return sphere_intersect(gptr(S.spheres) + 4 * (size_t)payload, ray, h);
+        case 1: return plane_intersect(gptr(S.planes) + 8 * (size_t)payload, ray, h);
+        case 2: return box_intersect(ld3(gptr(S.boxes) + 6 * (size_t)payload), ld3(gptr(S.boxes) + 6 * (size_t)payload + 3), ray, h);
+        default: return mesh_intersect(S.meshes[payload], ray, h, vc);
     }
 }
 
@@ -353,25 +407,27 @@ struct Closest { uint32_t obj, rank; double t, t2; float u, v; };
 // Scene::cast_ray_once (scene.rs:57-82): every object in scene order; the
 // stable sort by `near` keeps the lowest index among equals, i.e. a later
 // object must be strictly nearer to win.
-__device__ bool cast_closest(const DScene& S, const Ray& ray, Closest& c) {
+__device__ bool cast_closest(const DScene& S, const Ray& ray, Closest& c, Visits& vc) {
     c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
     bool any = false;
     const uint32_t n = S.n_objects;
+    const RT_GLOBAL DObject* objs = gptr(S.objects);
     for (uint32_t oi = 0; oi < n; oi++) {
-        const DObject o = S.objects[oi];
+        struct { uint32_t kind, payload, need_far; } o;
+        o.kind = objs[oi].kind; o.payload = objs[oi].payload; o.need_far = objs[oi].need_far;
         double near; bool hit;
-        if (o.kind == 0) hit = sphere_near(&S.spheres[4 * o.payload], ray, near);
-        else if (o.kind == 1) hit = plane_near(&S.planes[8 * o.payload], ray, near);
-        else if (o.kind == 2) hit = box_near(&S.boxes[6 * o.payload], ray, near);
+        if (o.kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)o.payload, ray, near);
+        else if (o.kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)o.payload, ray, near);
+        else if (o.kind == 2) hit = box_near(gptr(S.boxes) + 6 * (size_t)o.payload, ray, near);
         else {
             MeshHit mh;
             if (o.need_far) {
-                hit = mesh_traverse<TRAV_TWO>(S.meshes[o.payload], ray, INFINITY, mh);
+                hit = mesh_traverse<TRAV_TWO>(S.meshes[o.payload], ray, INFINITY, mh, vc);
                 if (hit && (!any || mh.t0 < c.t)) {
                     c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.n >= 2 ? mh.t1 : mh.t0; c.u = mh.u; c.v = mh.v; any = true;
                 }
             } else {
-                hit = mesh_traverse<TRAV_CLOSEST>(S.meshes[o.payload], ray, any ? c.t : INFINITY, mh);
+                hit = mesh_traverse<TRAV_CLOSEST>(S.meshes[o.payload], ray, any ? c.t : INFINITY, mh, vc);
                 if (hit) { c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.t0; c.u = mh.u; c.v = mh.v; any = true; }
             }
             continue;
@@ -383,17 +439,19 @@ __device__ bool cast_closest(const DScene& S, const Ray& ray, Closest& c) {
 
 // Shadow casts.  sun.rs:89: any object the ray hits at all; point.rs:91-92:
 // the nearest hit has near <= dist, i.e. some object has near <= dist.
-__device__ bool cast_any(const DScene& S, const Ray& ray, bool limited, double dist) {
+__device__ bool cast_any(const DScene& S, const Ray& ray, bool limited, double dist, Visits& vc) {
     const uint32_t n = S.n_objects;
+    const RT_GLOBAL DObject* objs = gptr(S.objects);
     for (uint32_t oi = 0; oi < n; oi++) {
-        const DObject o = S.objects[oi];
+        struct { uint32_t kind, payload; } o;
+        o.kind = objs[oi].kind; o.payload = objs[oi].payload;
         double near; bool hit;
-        if (o.kind == 0) hit = sphere_near(&S.spheres[4 * o.payload], ray, near);
-        else if (o.kind == 1) hit = plane_near(&S.planes[8 * o.payload], ray, near);
-        else if (o.kind == 2) hit = box_near(&S.boxes[6 * o.payload], ray, near);
+        if (o.kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)o.payload, ray, near);
+        else if (o.kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)o.payload, ray, near);
+        else if (o.kind == 2) hit = box_near(gptr(S.boxes) + 6 * (size_t)o.payload, ray, near);
         else {
             MeshHit mh;
-            if (mesh_traverse<TRAV_ANY>(S.meshes[o.payload], ray, limited ? dist : INFINITY, mh)) return true;
+            if (mesh_traverse<TRAV_ANY>(S.meshes[o.payload], ray, limited ? dist : INFINITY, mh, vc)) return true;
             continue;
         }
         if (hit && (!limited || near <= dist)) return true;
@@ -403,20 +461,20 @@ __device__ bool cast_any(const DScene& S, const Ray& ray, bool limited, double d
 
 // Rebuilds the full Hit of the closest object from the trace record
 __device__ void closest_hit_fill(const DScene& S, const Ray& ray, uint32_t obj, uint32_t rank, double t, double t2, float u, float v, Hit& h) {
-    const DObject o = S.objects[obj];
-    if (o.kind == 3) mesh_hit_fill(S.meshes[o.payload], ray, rank, t, t2, u, v, h);
-    else object_intersect(S, obj, ray, h);
+    const RT_GLOBAL DObject* op = gptr(S.objects) + obj;
+    if (op->kind == 3) mesh_hit_fill(S.meshes[op->payload], ray, rank, t, t2, u, v, h);
+    else { Visits none; none.nodes = 0; none.tris = 0; object_intersect(S, obj, ray, h, none); }   // never a mesh here
 }
 
 // ---------------------------------------------------------------- material.rs:119-141
-DEV uint32_t ldrgb(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+template <typename P> DEV uint32_t ldrgb(P p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
 DEV uint32_t texture_at(const DMaterial& m, float u, float v) {
     if (m.tex_kind == 0) return m.a_rgb;
     if (m.tex_kind == 1) {
         float w = (float)m.tex_w, h = (float)m.tex_h;
         uint32_t x = as_u32f(clampf(u * w, 0.f, w - 1.f));
         uint32_t y = as_u32f(clampf(v * h, 0.f, h - 1.f));
-        return ldrgb(&m.tex_rgb[3 * ((size_t)y * m.tex_w + x)]);
+        return ldrgb(gptr(m.tex_rgb) + 3 * ((size_t)y * m.tex_w + x));
     }
     bool a = u > 0.5f, b = v > 0.5f;
     return a == b ? m.a_rgb : m.b_rgb;
@@ -426,7 +484,7 @@ DEV uint32_t texture_at(const DMaterial& m, float u, float v) {
 DEV uint32_t sky_px(const DScene& S, double xx, double yy) {
     uint32_t xi = as_u32d(xx), yi = as_u32d(yy);
     if (xi >= S.sky_w || yi >= S.sky_h) return 0u;   // the reference's get_pixel would panic
-    return ldrgb(&S.sky_pix[3 * ((size_t)yi * S.sky_w + xi)]);
+    return ldrgb(gptr(S.sky_pix) + 3 * ((size_t)yi * S.sky_w + xi));
 }
 __device__ uint32_t skybox_color(const DScene& S, D3 dir) {
     if (S.sky_kind == 0) return S.sky_rgb;                                                       // skybox.rs:17-21

@@ -8,20 +8,23 @@
 #define RT_METER 2.                /* lighting/mod.rs:13 */
 #define RT_NONE 0xFFFFFFFFu
 #define RT_MAX_STACK 64            /* deepest mesh BVH the traversal stack holds */
+#define RT_LDS_STACK 16            /* stack entries per lane kept in LDS; deeper ones spill to private memory */
 
 struct D3 { double x, y, z; };
 
 // One inner node of a mesh's top-down BVH (acceleration.rs:407-417), re-emitted
-// so that a single 128-byte fetch carries BOTH children's boxes: a visit tests
-// the two boxes it needs next without touching the children themselves.
-// Boxes are stored as centre + half size, the two quantities the reference's
-// slab test derives from min/max on every call (acceleration.rs:76,135).
+// compactly: a single 64-byte fetch (four 16-byte loads) carries BOTH children's
+// boxes and references, so a visit tests the two boxes it needs next without
+// touching the children themselves.  The boxes are f32, rounded OUTWARD from the
+// reference's f64 slab bounds (centroid -+ size, acceleration.rs:76,135): they
+// are used for culling only -- a box test that passes in the reference passes
+// here -- while every triangle test stays f64 and exact.
 #define RT_LEAF_BIT 0x80000000u
 struct __attribute__((aligned(16))) DNode {
-    double lc[3], lh[3];   // child a: centre, half size
-    double rc[3], rh[3];   // child b
-    uint32_t lref, rref;   // inner child: node index; leaf child: RT_LEAF_BIT | first triangle (leaf order)
-    uint32_t pad[6];
+    float lmin[3], lmax[3];   // child a
+    float rmin[3], rmax[3];   // child b
+    uint32_t lref, rref;      // inner child: node index; leaf child: RT_LEAF_BIT | first triangle (leaf order)
+    uint32_t pad[2];
 };
 
 // One triangle in leaf order (the order mesh.rs:326-345 gathers candidates):
@@ -36,7 +39,7 @@ struct DMesh {
     const float* texcoords;    // [n][2]
     const uint32_t* tri_nrm;   // [n_tris][3], mesh order
     const uint32_t* tri_uv;    // [n_tris][3] or null
-    double root_c[3], root_h[3];
+    float root_min[3], root_max[3];   // the root's own box, f32 rounded outward
     uint32_t n_inner, n_tris, n_texcoords;
     uint32_t root_ref;         // 0 (inner node 0), or RT_LEAF_BIT | 0 when the root itself is a leaf
 };
@@ -105,4 +108,6 @@ enum { NF_DONE = 1, NF_TRANSPARENT = 2, NF_T_REFLECT = 4, NF_REFLECT = 8, NF_EMI
 struct DCounters {
     unsigned long long rays_primary, rays_reflect, rays_transmit, rays_shadow;
     unsigned long long next_count;   // rays appended to the next level
+    unsigned long long hit_count;    // rays of the current level that hit something (length of the hit list)
+    unsigned long long nodes_visited, tris_tested;   // instrumented kernel variants only
 };

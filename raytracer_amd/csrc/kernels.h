@@ -3,9 +3,12 @@
 // The reference runs trace_ray recursively per pixel (scene.rs:85-206) and
 // quantises every call's result to 8 bits before the caller mixes it in.  Here
 // each recursion depth is one "level": a flat array of rays.  Per level,
-//   k_trace   finds every ray's closest hit            (scene.rs:97, cast_ray_once)
-//   k_shade   rebuilds the Hit, samples the texture, runs the lights with their
-//             shadow rays, and appends the child rays to the next level
+//   k_trace   finds every ray's closest hit and lists the rays that hit something
+//                                                      (scene.rs:97, cast_ray_once)
+//   k_shadow  one thread per (hit ray, light): the light's shadow cast
+//                                                      (sun.rs:87-94, point.rs:89-99)
+//   k_shade   rebuilds the Hit, samples the texture, sums the lights using the
+//             shadow results, and appends the child rays to the next level
 //                                                      (scene.rs:102-196)
 // and, once the deepest level is done, levels are folded back bottom-up by
 //   k_resolve which applies the lerps of scene.rs:176-202 to the children's
@@ -13,7 +16,7 @@
 #pragma once
 #include "dev_rt.h"
 
-#define RT_BLOCK 256
+#define RT_BLOCK RT_BLOCK_DIM
 #define RT_INACTIVE 0xFFFFFFFEu   // padding slot of an edge tile
 
 struct ShardMap {
@@ -54,22 +57,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(const DScene* Sp, DLevel L
     store_ray(L, i, ld3(S.cam_o), camera_direction(S, (double)x, (double)y));
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, uint32_t n) {
-    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    if (L.hit_obj[i] == RT_INACTIVE) return;
-    const DScene& S = *Sp;
-    Ray ray = load_ray(L, i);
-    Closest c;
-    cast_closest(S, ray, c);
-    L.hit_obj[i] = c.obj; L.hit_prim[i] = c.rank;
-    L.hit_t[i] = c.t; L.hit_t2[i] = c.t2; L.hit_u[i] = c.u; L.hit_v[i] = c.v;
-}
-
 DEV uint32_t lane_id() { return __lane_id(); }
 DEV unsigned long long lanes_below() { return (1ull << lane_id()) - 1ull; }
 
-// Appends one slot per flagged lane of the wave to the next level; one atomic per wave.
+// Appends one slot per flagged lane of the wave; one atomic per wave.
 DEV uint32_t wave_append(bool want, unsigned long long* counter) {
     unsigned long long mask = __ballot(want);
     uint32_t total = (uint32_t)__popcll(mask);
@@ -87,41 +78,100 @@ DEV void wave_count(uint32_t v, unsigned long long* counter) {
     if (lane_id() == 0 && v) atomicAdd(counter, (unsigned long long)v);
 }
 
-// One light's contribution (lighting/sun.rs:72-97, point.rs:66-105); returns
-// false when the light contributes LightShading::default() (point.rs:72-74).
-__device__ bool light_shading(const DScene& S, const DLight& Lt, const Ray& ray, const Hit& hit,
-                              double& diffuse, double& specular, double& intensity, uint32_t& n_shadow) {
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, uint32_t n, uint32_t* hitlist, DCounters* C) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const DScene& S = *Sp;
+    bool hit = false;
+    Visits vc; vc.nodes = 0; vc.tris = 0;
+    if (i < n && L.hit_obj[i] != RT_INACTIVE) {
+        Ray ray = load_ray(L, i);
+        Closest c;
+        hit = cast_closest(S, ray, c, vc);
+        L.hit_obj[i] = c.obj; L.hit_prim[i] = c.rank;
+        L.hit_t[i] = c.t; L.hit_t2[i] = c.t2; L.hit_u[i] = c.u; L.hit_v[i] = c.v;
+    }
+    // rays that hit something, in wave order: the work list of k_shadow
+    uint32_t slot = wave_append(hit, &C->hit_count);
+    if (hit) hitlist[slot] = i;
+    if (COUNT) { wave_count(vc.nodes, &C->nodes_visited); wave_count(vc.tris, &C->tris_tested); }
+}
+
+// The shadow ray of one light at one hit (sun.rs:87-89, point.rs:68-76,89-91); false when the light casts none
+// there (sun without shadows; point light beyond max_distance, which contributes LightShading::default()).
+DEV bool shadow_ray_for(const DLight& Lt, const Hit& hit, Ray& sr, bool& limited, double& dist) {
+    if (Lt.kind == 0) {
+        if (!Lt.shadows) return false;
+        sr = ray_new(hit.vnear + hit.normal * RT_EPSILON, -ld3(Lt.v));
+        limited = false; dist = 0.;
+        return true;
+    }
+    D3 lvec = ld3(Lt.v) - hit.vnear;
+    dist = magnitude(lvec);
+    if (dist > Lt.max_distance) return false;
+    lvec = lvec / dist;
+    sr = ray_new(hit.vnear + hit.normal * RT_EPSILON, lvec);
+    limited = true;
+    return true;
+}
+
+// One thread per (ray that hit, light): the light's shadow cast.  Lanes of a wave share the light and walk
+// neighbouring hit points, so their shadow rays are coherent.  occ[light * stride + ray] = 1 when shadowed.
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(const DScene* Sp, DLevel L, const uint32_t* hitlist, uint8_t* occ, uint32_t stride, DCounters* C) {
+    const uint32_t h = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t li = blockIdx.y;
+    const DScene& S = *Sp;
+    Visits vc; vc.nodes = 0; vc.tris = 0;
+    uint32_t cast = 0;
+    if (h < (uint32_t)C->hit_count) {
+        const uint32_t i = hitlist[h];
+        const uint32_t obj = L.hit_obj[i];
+        const DMaterial& mat = S.materials[S.objects[obj].material];
+        if (!(mat.emissivity == 1.)) {                                  // scene.rs:105-107: no lighting at all
+            const DLight& Lt = S.lights[li];
+            Ray ray = load_ray(L, i);
+            Hit hit;
+            closest_hit_fill(S, ray, obj, L.hit_prim[i], L.hit_t[i], L.hit_t2[i], L.hit_u[i], L.hit_v[i], hit);
+            Ray sr; bool limited; double dist;
+            if (shadow_ray_for(Lt, hit, sr, limited, dist)) {
+                cast = 1;
+                occ[(size_t)li * stride + i] = cast_any(S, sr, limited, dist, vc) ? 1 : 0;
+            }
+        }
+    }
+    wave_count(cast, &C->rays_shadow);
+    if (COUNT) { wave_count(vc.nodes, &C->nodes_visited); wave_count(vc.tris, &C->tris_tested); }
+}
+
+// One light's contribution (lighting/sun.rs:72-97, point.rs:66-105) given its shadow cast's result
+DEV void light_shading(const DLight& Lt, const Ray& ray, const Hit& hit, bool shadowed,
+                       double& diffuse, double& specular, double& intensity) {
     const double FMAX = 1.7976931348623157e308;
     if (Lt.kind == 0) {
         D3 lvec = -ld3(Lt.v);
         diffuse = clampd(dot(hit.normal, lvec), 0., FMAX);
         D3 halfway = normalize(lvec - ray.d);
         specular = rt_powi(clampd(dot(hit.normal, halfway), 0., FMAX), Lt.specular_power);
-        if (Lt.shadows) {
-            Ray sr = ray_new(hit.vnear + hit.normal * RT_EPSILON, lvec);
-            n_shadow++;
-            if (cast_any(S, sr, false, 0.)) { diffuse *= Lt.shadow_coefficient; specular *= Lt.shadow_coefficient; }
-        }
+        if (Lt.shadows && shadowed) { diffuse *= Lt.shadow_coefficient; specular *= Lt.shadow_coefficient; }
         intensity = Lt.intensity;
-        return true;
+        return;
     }
     D3 lvec = ld3(Lt.v) - hit.vnear;
     double dist = magnitude(lvec);
-    if (dist > Lt.max_distance) return false;
+    if (dist > Lt.max_distance) { diffuse = 0.; specular = 0.; intensity = 0.; return; }   // LightShading::default()
     lvec = lvec / dist;
     diffuse = clampd(dot(hit.normal, lvec), 0., FMAX);
     D3 halfway = normalize(lvec - ray.d);
     specular = rt_powi(clampd(dot(hit.normal, halfway), 0., FMAX), Lt.specular_power);
-    Ray sr = ray_new(hit.vnear + hit.normal * RT_EPSILON, lvec);
-    n_shadow++;
-    if (cast_any(S, sr, true, dist)) { diffuse *= 0.; specular *= 0.; }
+    if (shadowed) { diffuse *= 0.; specular *= 0.; }
     double q = dist / RT_METER;
     intensity = Lt.intensity / (q * q);
-    return true;
 }
 
+template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, DLevel N, uint32_t n, uint32_t depth,
-                                                    uint32_t next_cap, DCounters* C, uint32_t* ids_out, ShardMap map) {
+                                                    uint32_t next_cap, DCounters* C, uint32_t* ids_out, const uint8_t* occ, uint32_t stride) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     const DScene& S = *Sp;
     bool active = i < n;
@@ -131,7 +181,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, 
         if (ids_out && depth == 0) { ids_out[2 * (size_t)i] = RT_NONE; ids_out[2 * (size_t)i + 1] = RT_NONE; }
         active = false;
     }
-    uint32_t n_shadow = 0;
+    Visits vc; vc.nodes = 0; vc.tris = 0;
     bool want0 = false, want1 = false;
     D3 c0o = d3(0, 0, 0), c0d = d3(0, 0, 1), c1o = d3(0, 0, 0), c1d = d3(0, 0, 1);
 
@@ -156,7 +206,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, 
                 for (uint32_t li = 0; li < S.n_lights; li++) {
                     const DLight& Lt = S.lights[li];
                     double diff = 0., spec = 0., inten = 0.;
-                    light_shading(S, Lt, ray, hit, diff, spec, inten, n_shadow);
+                    light_shading(Lt, ray, hit, occ[(size_t)li * stride + i] != 0, diff, spec, inten);
                     D3 lcol = ld3(Lt.col);
                     D3 dv = lcol * diff;
                     D3 sv = lcol * (spec * Lt.specular_strength);
@@ -174,9 +224,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, 
                         D3 ref_vec;
                         if (refraction_vec(ray.d, hit.normal, 1., ior, ref_vec)) {           // :140 (the reference unwraps)
                             Hit ref_hit;
-                            if (object_intersect(S, obj, ray_new(hit.vnear - ref_vec, ref_vec), ref_hit)) {              // :143
+                            if (object_intersect(S, obj, ray_new(hit.vnear - ref_vec, ref_vec), ref_hit, vc)) {              // :143
                                 Hit exit_hit;
-                                if (object_intersect(S, obj, ray_new(ref_hit.vfar + ref_vec, -ref_vec), exit_hit)) {     // :145-146
+                                if (object_intersect(S, obj, ray_new(ref_hit.vfar + ref_vec, -ref_vec), exit_hit, vc)) {     // :145-146
                                     D3 exit_ref_vec;
                                     if (refraction_vec(ref_vec, -exit_hit.normal, ior, 1., exit_ref_vec)) {              // :148-153
                                         want0 = true; c0o = ref_hit.vfar + exit_ref_vec * RT_EPSILON; c0d = exit_ref_vec;  // :155
@@ -228,9 +278,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, 
     }
     if (want0) { store_ray(N, s0, c0o, c0d); N.hit_obj[s0] = RT_NONE; }
     if (want1) { store_ray(N, s1, c1o, c1d); N.hit_obj[s1] = RT_NONE; }
-    wave_count(n_shadow, &C->rays_shadow);
     wave_count(want0 ? 1u : 0u, &C->rays_transmit);
     wave_count(want1 ? 1u : 0u, &C->rays_reflect);
+    if (COUNT) { wave_count(vc.nodes, &C->nodes_visited); wave_count(vc.tris, &C->tris_tested); }
 }
 
 // Folds one level into its parents' view: scene.rs:176-205 on the children's
@@ -310,7 +360,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(const DScene* Sp, const doub
     bool any = false; uint32_t best = RT_NONE; Hit bh;
     for (uint32_t oi = 0; oi < S.n_objects; oi++) {
         Hit h;
-        if (object_intersect(S, oi, ray, h) && (!any || h.near < bh.near)) { any = true; best = oi; bh = h; }
+        Visits vc; vc.nodes = 0; vc.tris = 0;
+        if (object_intersect(S, oi, ray, h, vc) && (!any || h.near < bh.near)) { any = true; best = oi; bh = h; }
     }
     if (any) {
         o.object = best; o.prim = bh.prim; o.near_t = bh.near; o.far_t = bh.far;

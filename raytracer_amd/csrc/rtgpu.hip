@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -41,6 +42,10 @@ struct rt_ctx {
     void* d_out = nullptr; size_t d_out_cap = 0;      // rgb staging for rt_render
     void* d_ids = nullptr; size_t d_ids_cap = 0;      // compact ids
     void* d_ids2 = nullptr; size_t d_ids2_cap = 0;    // row-major ids
+    void* d_hitlist = nullptr; size_t d_hitlist_cap = 0;   // rays of the current level that hit something
+    void* d_occ = nullptr; size_t d_occ_cap = 0;      // shadow results [light][ray] of the current level
+    bool count_visits = false;                        // RTGPU_COUNT_VISITS=1: instrumented kernels
+    uint32_t n_lights = 0;
     hipEvent_t ev[8];
     size_t scene_bytes = 0, work_bytes = 0;
     double ms_upload = 0.;
@@ -145,11 +150,18 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
     for (uint32_t i = 0; i < NN; i++) if (seen[i] && m.nodes[i].count == 0) inner_id[i] = n_inner++;
     for (uint32_t i = 0; i < m.n_prims; i++) if (m.prim_indices[i] >= m.n_tris) return fail(c, RT_ERR_INVALID, "mesh BVH: primitive index out of range");
 
-    auto box_of = [&](uint32_t i, double* cen, double* half) {
+    // f32 box of node i, rounded outward from the slab bounds the reference's test uses:
+    // centroid -+ size with centroid = (min+max)*0.5 and size = max - centroid (acceleration.rs:76,135)
+    auto box_of = [&](uint32_t i, float* bmin, float* bmax) {
         const rt_bvh_node& nd = m.nodes[i];
         for (int k = 0; k < 3; k++) {
-            cen[k] = (nd.min[k] + nd.max[k]) * 0.5;   // acceleration.rs:76
-            half[k] = nd.max[k] - cen[k];             // acceleration.rs:135
+            const double cen = (nd.min[k] + nd.max[k]) * 0.5;
+            const double half = nd.max[k] - cen;
+            const double lo = std::fmin(nd.min[k], cen - half), hi = std::fmax(nd.max[k], cen + half);
+            float flo = (float)lo, fhi = (float)hi;
+            if ((double)flo > lo) flo = std::nextafterf(flo, -INFINITY);
+            if ((double)fhi < hi) fhi = std::nextafterf(fhi, INFINITY);
+            bmin[k] = flo; bmax[k] = fhi;
         }
     };
     auto ref_of = [&](uint32_t i) -> uint32_t {
@@ -164,8 +176,8 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
         if (nd.count == 0) {
             DNode& dn = nodes[inner_id[i]];
             std::memset(&dn, 0, sizeof(dn));
-            box_of(i + 1, dn.lc, dn.lh);
-            box_of(nd.right_or_first, dn.rc, dn.rh);
+            box_of(i + 1, dn.lmin, dn.lmax);
+            box_of(nd.right_or_first, dn.rmin, dn.rmax);
             dn.lref = ref_of(i + 1); dn.rref = ref_of(nd.right_or_first);
         } else {
             last[nd.right_or_first + nd.count - 1] = 1;
@@ -182,7 +194,7 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
         dt.orig = t; dt.last = last[r];
     }
     if (!last[m.n_prims - 1]) return fail(c, RT_ERR_INVALID, "mesh BVH: leaf list does not end on a leaf boundary");
-    box_of(0, out.root_c, out.root_h);
+    box_of(0, out.root_min, out.root_max);
     out.root_ref = m.nodes[0].count == 0 ? 0u : (RT_LEAF_BIT | m.nodes[0].right_or_first);
     out.n_inner = n_inner; out.n_tris = m.n_tris; out.n_texcoords = m.tri_uv ? m.n_texcoords : 0;
     int rc;
@@ -272,7 +284,8 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
 
     std::vector<uint32_t> counts;
     counts.push_back(n0);
-    float ms_trace = 0.f, ms_shade = 0.f, ms_resolve = 0.f;
+    float ms_trace = 0.f, ms_shadow = 0.f, ms_shade = 0.f, ms_resolve = 0.f;
+    uint32_t n_tr = 0, n_sh = 0, n_sd = 0;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     int rc;
     if (n0 > 0) {
@@ -286,20 +299,37 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
         const bool can_spawn = depth < c->max_depth;
         const size_t next_cap = can_spawn ? std::min<size_t>((size_t)2 * n, 0x7FFFFFFEull) : 1;
         if ((rc = ensure_level(c, depth + 1, next_cap)) != RT_OK) return rc;
+        if ((rc = ensure_buf(c, &c->d_hitlist, &c->d_hitlist_cap, (size_t)n * 4)) != RT_OK) return rc;
+        if (c->n_lights && (rc = ensure_buf(c, &c->d_occ, &c->d_occ_cap, (size_t)n * c->n_lights)) != RT_OK) return rc;
+        uint32_t* hitlist = static_cast<uint32_t*>(c->d_hitlist);
+        uint8_t* occ = static_cast<uint8_t*>(c->d_occ);
         const dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
         HIP_TRY(c, hipEventRecord(c->ev[1], s));
-        hipLaunchKernelGGL(k_trace, grid, block, 0, s, c->dscene, c->levels[depth].lv, n);
+        if (c->count_visits) hipLaunchKernelGGL(k_trace<true>, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, c->dcounters);
+        else hipLaunchKernelGGL(k_trace<false>, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, c->dcounters);
         HIP_TRY(c, hipEventRecord(c->ev[2], s));
-        hipLaunchKernelGGL(k_shade, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, depth,
-                           (uint32_t)next_cap, c->dcounters, depth == 0 ? d_ids : nullptr, map);
+        if (c->n_lights) {
+            // sized for the worst case (every ray hit); threads past the hit count leave at once
+            const dim3 sgrid((n + RT_BLOCK - 1) / RT_BLOCK, c->n_lights);
+            if (c->count_visits) hipLaunchKernelGGL(k_shadow<true>, sgrid, block, 0, s, c->dscene, c->levels[depth].lv, hitlist, occ, n, c->dcounters);
+            else hipLaunchKernelGGL(k_shadow<false>, sgrid, block, 0, s, c->dscene, c->levels[depth].lv, hitlist, occ, n, c->dcounters);
+            n_sd++;
+        }
+        HIP_TRY(c, hipEventRecord(c->ev[6], s));
+        if (c->count_visits) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, depth,
+                                                (uint32_t)next_cap, c->dcounters, depth == 0 ? d_ids : nullptr, occ, n);
+        else hipLaunchKernelGGL(k_shade<false>, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, depth,
+                                (uint32_t)next_cap, c->dcounters, depth == 0 ? d_ids : nullptr, occ, n);
+        n_tr++; n_sh++;
         HIP_TRY(c, hipEventRecord(c->ev[3], s));
         HIP_TRY(c, hipMemcpyAsync(c->hcounters, c->dcounters, sizeof(DCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         HIP_TRY(c, hipGetLastError());
-        float a = 0.f, b = 0.f;
+        float a = 0.f, b = 0.f, b2 = 0.f;
         (void)hipEventElapsedTime(&a, c->ev[1], c->ev[2]);
-        (void)hipEventElapsedTime(&b, c->ev[2], c->ev[3]);
-        ms_trace += a; ms_shade += b;
+        (void)hipEventElapsedTime(&b2, c->ev[2], c->ev[6]);
+        (void)hipEventElapsedTime(&b, c->ev[6], c->ev[3]);
+        ms_trace += a; ms_shadow += b2; ms_shade += b;
         const unsigned long long spawned = c->hcounters->next_count;
         if (spawned > next_cap) return fail(c, RT_ERR_DEVICE, "wavefront level overflow");
         if (spawned > 0 && can_spawn) {
@@ -307,7 +337,7 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
             if (depth + 1 < 8) stats.rays_per_level[depth + 1] = spawned;
         }
         // children of this level were appended at [0, spawned) of the next level: restart its counter
-        HIP_TRY(c, hipMemsetAsync(&c->dcounters->next_count, 0, sizeof(unsigned long long), s));
+        HIP_TRY(c, hipMemsetAsync(&c->dcounters->next_count, 0, 2 * sizeof(unsigned long long), s));   // next_count, hit_count
     }
     HIP_TRY(c, hipEventRecord(c->ev[4], s));
     for (int depth = (int)counts.size() - 1; depth >= 0; depth--) {
@@ -325,7 +355,9 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
     stats.rays_reflect = c->hcounters->rays_reflect;
     stats.rays_transmit = c->hcounters->rays_transmit;
     stats.rays_shadow = c->hcounters->rays_shadow;
-    stats.ms_render = ms_all; stats.ms_trace = ms_trace; stats.ms_shade = ms_shade; stats.ms_resolve = ms_resolve;
+    stats.ms_render = ms_all; stats.ms_trace = ms_trace; stats.ms_shadow = ms_shadow; stats.ms_shade = ms_shade; stats.ms_resolve = ms_resolve;
+    stats.nodes_visited = c->hcounters->nodes_visited; stats.tris_tested = c->hcounters->tris_tested;
+    stats.launches_trace = n_tr; stats.launches_shadow = n_sd; stats.launches_shade = n_sh;
     stats.ms_upload = c->ms_upload;
     stats.device_bytes = c->scene_bytes + c->work_bytes;
     if (st) *st = stats;
@@ -353,6 +385,7 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     rt_ctx* c = new (std::nothrow) rt_ctx();
     if (!c) { g_create_error = "out of host memory"; return RT_ERR_NOMEM; }
     c->device = device_id;
+    { const char* e = std::getenv("RTGPU_COUNT_VISITS"); c->count_visits = e && e[0] == '1'; }
     auto bail = [&](const char* what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); delete c; return RT_ERR_DEVICE; };
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
@@ -373,6 +406,8 @@ void rt_ctx_destroy(rt_ctx* c) {
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ids) (void)hipFree(c->d_ids);
     if (c->d_ids2) (void)hipFree(c->d_ids2);
+    if (c->d_hitlist) (void)hipFree(c->d_hitlist);
+    if (c->d_occ) (void)hipFree(c->d_occ);
     if (c->dscene) (void)hipFree(c->dscene);
     if (c->dcounters) (void)hipFree(c->dcounters);
     if (c->hcounters) (void)hipHostFree(c->hcounters);
@@ -489,7 +524,7 @@ int rt_scene_upload(rt_ctx* c, const rt_scene_desc* d) {
         if ((rc = upload(c, d->skybox.rgb, (size_t)d->skybox.w * d->skybox.h * 3, &H.sky_pix)) != RT_OK) return rc;
     }
     HIP_TRY(c, hipMemcpy(c->dscene, &H, sizeof(DScene), hipMemcpyHostToDevice));
-    c->vw = H.vw; c->vh = H.vh; c->max_depth = H.max_depth;
+    c->vw = H.vw; c->vh = H.vh; c->max_depth = H.max_depth; c->n_lights = H.n_lights;
     c->have_scene = true;
     c->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;

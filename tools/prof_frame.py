@@ -1,0 +1,18 @@
+"""Renders a few frames of the benchmark scene with nothing else around them: the program to put under rocprofv3."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracer_amd as ra  # noqa: E402
+from raytracer_amd import scenes  # noqa: E402
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+cells = int(sys.argv[2]) if len(sys.argv) > 2 else 708
+w, h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (3840, 2160)
+s = scenes.synthetic_terrain_scene(w, h, cells=cells)
+ctx = ra.Context(0)
+ctx.upload(s)
+for _ in range(frames):
+    rgb, _, st = ctx.render()
+print(f"frames {frames} ms {st.ms_render:.3f} trace {st.ms_trace:.3f} shadow {st.ms_shadow:.3f} shade {st.ms_shade:.3f} rays {st.rays} nodes {st.nodes_visited} tris {st.tris_tested}")
+ctx.close()
