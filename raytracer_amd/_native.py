@@ -62,6 +62,8 @@ class RthMaterial(C.Structure):
 
 def _load(name):
     path = os.path.join(_HERE, name)
+    if name == "librtgpu.so" and os.environ.get("RTGPU_LIB"):
+        path = os.environ["RTGPU_LIB"]          # development: an experimental build of the same ABI
     if not os.path.exists(path):
         raise OSError(f"{path} is missing: build it with `make` (or __graft_entry__.build()) before use")
     return C.CDLL(path, mode=C.RTLD_GLOBAL)

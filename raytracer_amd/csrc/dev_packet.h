@@ -1,0 +1,222 @@
+// Wave-coherent ray packets: the 64 rays of a wave walk a mesh BVH TOGETHER.
+//
+// Primary rays of an 8x8 pixel block and the shadow rays of neighbouring hit points towards one light pass
+// through nearly the same nodes.  Walked lane by lane, every lane fetches its own copy of every node through
+// the vector memory path, whose L1-to-register bandwidth (64 B/clk per CU) then bounds the kernel.  Here the
+// wave keeps ONE traversal state -- current node, stack, and per node the mask of lanes whose ray entered it --
+// in scalar registers and LDS; node and triangle records are fetched once per wave with scalar loads, and each
+// lane only runs the box / triangle arithmetic against its own ray.  A node is visited when ANY lane needs it.
+//
+// Results are those of the per-lane walk (and of the reference, mesh.rs:326-439): a lane tests exactly the
+// triangles of leaves whose box chain its own ray passed, with the same exact f64 triangle test, keeps the
+// nearest hit with ties to the lower leaf-order index, and only the ORDER of the tests differs.
+#pragma once
+#include "dev_rt.h"
+
+#define RT_CONST __attribute__((address_space(4)))   /* constant address space: uniform addresses load through the scalar cache */
+typedef unsigned int __attribute__((ext_vector_type(4))) rt_u4;
+
+#define RT_PSTACK 64   /* packet stack entries per wave (16 bytes each) */
+__shared__ rt_u4 rt_pstack[(RT_BLOCK_DIM / 64) * RT_PSTACK];
+
+DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+DEV unsigned long long uni64(unsigned long long v) { return ((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
+template <typename T> DEV const T* uni_ptr(const T* p) { return (const T*)uni64((unsigned long long)p); }
+DEV bool lane_in(unsigned long long mask) { return (mask >> __lane_id()) & 1ull; }
+DEV float asf(uint32_t u) { return __uint_as_float(u); }
+DEV float first_lane_f(float v, unsigned long long mask) {   // v of the lowest lane set in mask (mask != 0)
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), __ffsll((long long)mask) - 1));
+}
+DEV double mkd(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+
+// one node record, wave-uniform (scalar registers)
+struct UNode { rt_u4 minx, miny, minz, maxx, maxy, maxz, ref; };
+DEV UNode load_unode(const DNode* nodes, uint32_t idx) {
+    const RT_CONST rt_u4* p = (const RT_CONST rt_u4*)(nodes + idx);
+    UNode n;
+    n.minx = p[0]; n.miny = p[1]; n.minz = p[2]; n.maxx = p[3]; n.maxy = p[4]; n.maxz = p[5]; n.ref = p[6];
+    return n;
+}
+DEV TriData load_utri(const DTri* tris, uint32_t rank) {
+    const RT_CONST rt_u4* p = (const RT_CONST rt_u4*)(tris + rank);
+    const rt_u4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+    TriData t;
+    t.v0 = d3(mkd(a.x, a.y), mkd(a.z, a.w), mkd(b.x, b.y));
+    t.e1 = d3(mkd(b.z, b.w), mkd(c.x, c.y), mkd(c.z, c.w));
+    t.e2 = d3(mkd(d.x, d.y), mkd(d.z, d.w), mkd(e.x, e.y));
+    t.orig = e.z; t.last = e.w;
+    return t;
+}
+
+// slab test of this lane's ray against child k of a uniform node
+#define RT_CHILD_TEST(n, k, ray, tn)                                                                                      \
+    slab_test((ray).nx ? asf((n).maxx[k]) : asf((n).minx[k]), (ray).ny ? asf((n).maxy[k]) : asf((n).miny[k]),            \
+              (ray).nz ? asf((n).maxz[k]) : asf((n).minz[k]), (ray).nx ? asf((n).minx[k]) : asf((n).maxx[k]),            \
+              (ray).ny ? asf((n).miny[k]) : asf((n).maxy[k]), (ray).nz ? asf((n).minz[k]) : asf((n).maxz[k]), (ray), (tn))
+
+// uniform compare-exchange on (key, ref, mask)
+#define RT_UCSWAP(ka, ra, ma, kb, rb, mb)                                     \
+    do {                                                                      \
+        if ((kb) < (ka)) {                                                    \
+            const float k_ = (ka); (ka) = (kb); (kb) = k_;                    \
+            const uint32_t r_ = (ra); (ra) = (rb); (rb) = r_;                 \
+            const unsigned long long m_ = (ma); (ma) = (mb); (mb) = m_;       \
+        }                                                                     \
+    } while (0)
+
+struct PStack {
+    rt_u4* base;   // this wave's entries
+    int sp;        // uniform
+    DEV void push(uint32_t ref, unsigned long long mask) {
+        rt_u4 e; e.x = ref; e.y = (uint32_t)mask; e.z = (uint32_t)(mask >> 32); e.w = 0;
+        base[sp] = e;   // every lane writes the same value to the same address
+        ++sp;
+    }
+    DEV void pop(uint32_t& ref, unsigned long long& mask) {
+        --sp;
+        const rt_u4 e = base[sp];
+        ref = uni(e.x);
+        mask = ((unsigned long long)uni(e.z) << 32) | uni(e.y);
+    }
+};
+
+// MODE: TRAV_CLOSEST (nearest hit with t < bound, per lane) or TRAV_ANY (any hit with t <= bound, per lane).
+// Every lane of the wave must call this; `active` says whether the lane carries a ray.
+// TRAV_ANY returns true in the lanes whose ray is blocked.
+template <int MODE>
+__device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, double bound, MeshHit& mh, Visits& vc) {
+    mh.n = 0; mh.t0 = bound; mh.t1 = bound; mh.r0 = 0;
+    const DNode* nodes = uni_ptr(Mg.nodes);
+    const DTri* tris = uni_ptr(Mg.tris);
+    float limit = __double2float_ru(bound);
+    bool found = false;
+
+    float tn_root;
+    const bool root_hit = active && node_box(Mg.root_min, Mg.root_max, ray, tn_root) && !(tn_root > limit);
+    unsigned long long curmask = __ballot(root_hit);
+    unsigned long long alive = curmask;             // lanes still looking (TRAV_ANY: not yet blocked)
+    if (!curmask) return false;
+    uint32_t cur = uni(Mg.root_ref);
+    PStack st; st.base = &rt_pstack[(threadIdx.x >> 6) * RT_PSTACK]; st.sp = 0;
+
+    while (true) {
+        if (cur & RT_LEAF_BIT) {
+            // ---- a leaf: every triangle, against the lanes that entered the leaf's box
+            uint32_t rank = cur & ~RT_LEAF_BIT;
+            const bool in = lane_in(curmask & alive);
+            while (true) {
+                const TriData T = load_utri(tris, rank);
+                double t; float u, v;
+                if (in) vc.tris++;
+                const bool hit = in && tri_test(T, ray, t, u, v);
+                if (MODE == TRAV_ANY) {
+                    if (hit && t <= bound) found = true;
+                } else if (hit) {
+                    if (t < mh.t0 || (t == mh.t0 && rank < mh.r0)) {
+                        mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v; mh.n = 1;
+                        limit = __double2float_ru(t);
+                    }
+                }
+                if (T.last) break;
+                ++rank;
+            }
+            if (MODE == TRAV_ANY) {
+                alive &= ~__ballot(found);
+                if (!alive) break;
+            }
+            cur = RT_POP;
+        } else {
+            // ---- an inner node: four boxes against every lane that entered the node
+            const UNode n = load_unode(nodes, cur);
+            const bool in = lane_in(curmask & alive);
+            if (in) vc.nodes++;
+            float t0, t1, t2, t3;
+            const bool h0 = RT_CHILD_TEST(n, 0, ray, t0), h1 = RT_CHILD_TEST(n, 1, ray, t1);
+            const bool h2 = RT_CHILD_TEST(n, 2, ray, t2), h3 = RT_CHILD_TEST(n, 3, ray, t3);
+            unsigned long long m0 = __ballot(in && h0 && !(t0 > limit)), m1 = __ballot(in && h1 && !(t1 > limit));
+            unsigned long long m2 = __ballot(in && h2 && !(t2 > limit)), m3 = __ballot(in && h3 && !(t3 > limit));
+            uint32_t r0 = n.ref[0], r1 = n.ref[1], r2 = n.ref[2], r3 = n.ref[3];
+            if (r2 == RT_NO_CHILD) m2 = 0;
+            if (r3 == RT_NO_CHILD) m3 = 0;
+            if (MODE != TRAV_ANY) {
+                // visit order: by the entry distance of the first lane in each child (rays of a packet agree mostly)
+                const float INF = asf(0x7F800000u);
+                float k0 = m0 ? first_lane_f(t0, m0) : INF, k1 = m1 ? first_lane_f(t1, m1) : INF;
+                float k2 = m2 ? first_lane_f(t2, m2) : INF, k3 = m3 ? first_lane_f(t3, m3) : INF;
+                RT_UCSWAP(k0, r0, m0, k1, r1, m1); RT_UCSWAP(k2, r2, m2, k3, r3, m3);
+                RT_UCSWAP(k0, r0, m0, k2, r2, m2); RT_UCSWAP(k1, r1, m1, k3, r3, m3);
+                RT_UCSWAP(k1, r1, m1, k2, r2, m2);
+            }
+            // children nobody entered have an empty mask; the first non-empty one is next, the rest are stacked
+            cur = RT_POP;
+            if (m3) { cur = r3; curmask = m3; }
+            if (m2) { if (cur != RT_POP) st.push(cur, curmask); cur = r2; curmask = m2; }
+            if (m1) { if (cur != RT_POP) st.push(cur, curmask); cur = r1; curmask = m1; }
+            if (m0) { if (cur != RT_POP) st.push(cur, curmask); cur = r0; curmask = m0; }
+        }
+        if (cur == RT_POP) {
+            while (st.sp > 0) {
+                uint32_t r; unsigned long long m;
+                st.pop(r, m);
+                if (m & alive) { cur = r; curmask = m; break; }
+            }
+            if (cur == RT_POP) break;
+        }
+    }
+    return MODE == TRAV_ANY ? found : (mh.n > 0);
+}
+
+// Scene::cast_ray_once for a whole wave (scene.rs:57-82): the object loop is uniform, meshes are walked as a
+// packet.  Every lane calls it; `active` lanes carry a ray.
+__device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active, Closest& c, Visits& vc) {
+    c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
+    bool any = false;
+    const uint32_t n = S.n_objects;
+    const RT_GLOBAL DObject* objs = gptr(S.objects);
+    for (uint32_t oi = 0; oi < n; oi++) {
+        const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload), need_far = uni(objs[oi].need_far);
+        double near = 0.; bool hit = false;
+        if (kind == 3) {
+            MeshHit mh;
+            if (need_far) {
+                if (active && mesh_traverse<TRAV_TWO>(S.meshes[payload], ray, INFINITY, mh, vc) && (!any || mh.t0 < c.t)) {
+                    c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.n >= 2 ? mh.t1 : mh.t0; c.u = mh.u; c.v = mh.v; any = true;
+                }
+            } else if (packet_traverse<TRAV_CLOSEST>(S.meshes[payload], ray, active, any ? c.t : INFINITY, mh, vc)) {
+                c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.t0; c.u = mh.u; c.v = mh.v; any = true;
+            }
+            continue;
+        }
+        if (active) {
+            if (kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
+            else if (kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)payload, ray, near);
+            else hit = box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
+        }
+        if (hit && (!any || near < c.t)) { c.obj = oi; c.rank = RT_NONE; c.t = near; any = true; }
+    }
+    return any;
+}
+
+// Shadow cast for a whole wave (sun.rs:89, point.rs:91-92)
+__device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bool limited, double dist, Visits& vc) {
+    const uint32_t n = S.n_objects;
+    const RT_GLOBAL DObject* objs = gptr(S.objects);
+    bool blocked = false;
+    for (uint32_t oi = 0; oi < n; oi++) {
+        const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload);
+        if (kind == 3) {
+            MeshHit mh;
+            if (packet_traverse<TRAV_ANY>(S.meshes[payload], ray, active && !blocked, limited ? dist : INFINITY, mh, vc)) blocked = true;
+            continue;
+        }
+        if (active && !blocked) {
+            double near; bool hit;
+            if (kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
+            else if (kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)payload, ray, near);
+            else hit = box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
+            if (hit && (!limited || near <= dist)) blocked = true;
+        }
+        if (!__ballot(active && !blocked)) break;
+    }
+    return blocked;
+}

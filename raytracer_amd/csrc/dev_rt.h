@@ -204,13 +204,10 @@ DEV bool box_intersect(D3 pos, D3 size, const Ray& ray, Hit& h) {
 // The slab test of acceleration.rs:134-151 in f32 on an outward-rounded box, made conservative: the entry
 // distance is pushed down and the exit distance up by 2^-20 relative, which covers the rounding of the two
 // subtractions, of 1/direction and of the product (<= 6 * 2^-24).  NaN slabs (0 * inf) are ignored by
-// fmaxf/fminf exactly as f64::max/min ignore them in the reference.
+// fmaxf/fminf exactly as f64::max/min ignore them in the reference.  (ax..az: the bounds the ray meets
+// first on each axis, bx..bz: the ones it meets last.)
 #define RT_CULL_SLACK 9.5367431640625e-07f
-template <typename FP>
-DEV bool node_box(FP bmin, FP bmax, const Ray& ray, float& tn_out) {
-    const float ax = ray.nx ? bmax[0] : bmin[0], bx = ray.nx ? bmin[0] : bmax[0];
-    const float ay = ray.ny ? bmax[1] : bmin[1], by = ray.ny ? bmin[1] : bmax[1];
-    const float az = ray.nz ? bmax[2] : bmin[2], bz = ray.nz ? bmin[2] : bmax[2];
+DEV bool slab_test(float ax, float ay, float az, float bx, float by, float bz, const Ray& ray, float& tn_out) {
     const float t1x = ((ax - ray.ohx) - ray.olx) * ray.mfx, t2x = ((bx - ray.ohx) - ray.olx) * ray.mfx;
     const float t1y = ((ay - ray.ohy) - ray.oly) * ray.mfy, t2y = ((by - ray.ohy) - ray.oly) * ray.mfy;
     const float t1z = ((az - ray.ohz) - ray.olz) * ray.mfz, t2z = ((bz - ray.ohz) - ray.olz) * ray.mfz;
@@ -221,11 +218,29 @@ DEV bool node_box(FP bmin, FP bmax, const Ray& ray, float& tn_out) {
     tn_out = tn;
     return !(tn > tf || tf < 0.f);
 }
+template <typename FP>
+DEV bool node_box(FP bmin, FP bmax, const Ray& ray, float& tn_out) {
+    return slab_test(ray.nx ? bmax[0] : bmin[0], ray.ny ? bmax[1] : bmin[1], ray.nz ? bmax[2] : bmin[2],
+                     ray.nx ? bmin[0] : bmax[0], ray.ny ? bmin[1] : bmax[1], ray.nz ? bmin[2] : bmax[2], ray, tn_out);
+}
 
 // mesh.rs:25-59 with the edges precomputed
+// mesh.rs:25-59 with the edges precomputed.  The 80-byte record is fetched as five 16-byte loads (one L1 tag
+// lookup each) rather than field by field.
+typedef double __attribute__((ext_vector_type(2))) rt_d2;
+struct TriData { D3 v0, e1, e2; uint32_t orig, last; };
 template <typename TP>
-DEV bool tri_test(TP T, const Ray& ray, double& t_out, float& u_out, float& v_out) {
-    D3 v0 = d3(T->v0[0], T->v0[1], T->v0[2]), edge1 = d3(T->e1[0], T->e1[1], T->e1[2]), edge2 = d3(T->e2[0], T->e2[1], T->e2[2]);
+DEV TriData tri_load(TP T) {
+    const RT_GLOBAL rt_d2* p = (const RT_GLOBAL rt_d2*)T;
+    const rt_d2 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+    TriData r;
+    r.v0 = d3(a.x, a.y, b.x); r.e1 = d3(b.y, c.x, c.y); r.e2 = d3(d.x, d.y, e.x);
+    const unsigned long long w = (unsigned long long)__double_as_longlong(e.y);
+    r.orig = (uint32_t)w; r.last = (uint32_t)(w >> 32);
+    return r;
+}
+DEV bool tri_test(const TriData& T, const Ray& ray, double& t_out, float& u_out, float& v_out) {
+    const D3 v0 = T.v0, edge1 = T.e1, edge2 = T.e2;
     D3 h = cross(ray.d, edge2);
     double a = dot(edge1, h);
     if (a > -RT_EPSILON && a < RT_EPSILON) return false;
@@ -283,73 +298,117 @@ enum { TRAV_CLOSEST = 0, TRAV_TWO = 1, TRAV_ANY = 2 };
 //   TRAV_CLOSEST: nearest hit with t < bound (strict).
 //   TRAV_TWO:     nearest and second nearest (Hit::far, mesh.rs:411-423).
 //   TRAV_ANY:     true as soon as one hit has t <= bound.
+#define RT_POP 0xFFFFFFFFu   /* "nothing left": has the leaf bit set, so it also ends the inner-node loop */
+
+// compare-exchange of (distance, reference) pairs: afterwards ta <= tb
+#define RT_CSWAP(ta, ra, tb, rb)                                              \
+    do {                                                                      \
+        const bool sw_ = (tb) < (ta);                                         \
+        const float tx_ = sw_ ? (tb) : (ta), ty_ = sw_ ? (ta) : (tb);         \
+        const uint32_t rx_ = sw_ ? (rb) : (ra), ry_ = sw_ ? (ra) : (rb);      \
+        (ta) = tx_; (tb) = ty_; (ra) = rx_; (rb) = ry_;                       \
+    } while (0)
+
 template <int MODE>
 __device__ bool mesh_traverse(const DMesh& M, const Ray& ray, double bound, MeshHit& mh, Visits& vc) {
     mh.n = 0; mh.t0 = bound; mh.t1 = bound; mh.r0 = 0;   // r0 = 0: a hit AT an outside bound never wins the tie
     float tn_root;
+#ifdef RT_EXP_NOTRAV
+    if (MODE == TRAV_ANY) return false;
+#endif
     if (!node_box(M.root_min, M.root_max, ray, tn_root)) return false;
 
     int sp = 0;
     volatile unsigned long long spill[RT_MAX_STACK - RT_LDS_STACK];
     const GNodePtr nodes = gptr(M.nodes);
     const GTriPtr tris = gptr(M.tris);
-    const uint32_t POP = 0xFFFFFFFFu;
     uint32_t cur = M.root_ref;
     // boxes entered beyond `limit` cannot hold the answer; kept in f32, rounded up so that the skip stays safe
     float limit = __double2float_ru(bound);
-    while (true) {
-        if (cur & RT_LEAF_BIT) {
-            uint32_t rank = cur & ~RT_LEAF_BIT;
-            while (true) {
-                const GTriPtr T = &tris[rank];
-                const uint32_t last = T->last;
-                double t; float u, v;
-                vc.tris++;
-                if (tri_test(T, ray, t, u, v)) {
-                    if (MODE == TRAV_ANY) {
-                        if (t <= bound) return true;
-                    } else if (MODE == TRAV_CLOSEST) {
-                        if (t < mh.t0 || (t == mh.t0 && rank < mh.r0)) {
-                            mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v; mh.n = 1;
-                            limit = __double2float_ru(t);
-                        }
-                    } else {
-                        if (mh.n == 0 || t < mh.t0 || (t == mh.t0 && rank < mh.r0)) {
-                            if (mh.n >= 1) { mh.t1 = mh.t0; mh.n = 2; } else mh.n = 1;
-                            mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v;
-                        } else if (mh.n == 1 || t < mh.t1) { mh.t1 = t; mh.n = 2; }
-                        if (mh.n == 2) limit = __double2float_ru(mh.t1);
-                    }
-                }
-                if (last) break;
-                ++rank;
-            }
-            cur = POP;
-        } else {
+    const float INF = __uint_as_float(0x7F800000u);
+
+    while (cur != RT_POP) {
+        // ---- inner nodes, until this lane holds a leaf (the lanes of a wave leave this loop together, so
+        //      the triangle tests below run with as many lanes as possible)
+        while (!(cur & RT_LEAF_BIT)) {
             const GNodePtr nd = &nodes[cur];
-            float tl, tr;
             vc.nodes++;
-            bool hl = node_box(nd->lmin, nd->lmax, ray, tl);
-            bool hr = node_box(nd->rmin, nd->rmax, ray, tr);
-            hl = hl && !(tl > limit);
-            hr = hr && !(tr > limit);
-            const uint32_t lref = nd->lref, rref = nd->rref;
-            if (hl && hr) {
-                // nearer first; equal entry distances keep a before b (the reference's order)
-                const bool left_first = !(tr < tl);
-                RT_STACK_PUSH(left_first ? rref : lref, left_first ? tr : tl);
-                cur = left_first ? lref : rref;
-            } else if (hl) cur = lref;
-            else if (hr) cur = rref;
-            else cur = POP;
-        }
-        if (cur == POP) {
-            while (sp > 0) {
-                uint2 e;
-                RT_STACK_POP(e);
-                if (!(__uint_as_float(e.y) > limit)) { cur = e.x; break; }
+            float t0, t1, t2, t3;
+            // near/far plane of each child on each axis, by the sign of the direction
+            const bool h0 = slab_test(ray.nx ? nd->maxx[0] : nd->minx[0], ray.ny ? nd->maxy[0] : nd->miny[0], ray.nz ? nd->maxz[0] : nd->minz[0],
+                                      ray.nx ? nd->minx[0] : nd->maxx[0], ray.ny ? nd->miny[0] : nd->maxy[0], ray.nz ? nd->minz[0] : nd->maxz[0], ray, t0);
+            const bool h1 = slab_test(ray.nx ? nd->maxx[1] : nd->minx[1], ray.ny ? nd->maxy[1] : nd->miny[1], ray.nz ? nd->maxz[1] : nd->minz[1],
+                                      ray.nx ? nd->minx[1] : nd->maxx[1], ray.ny ? nd->miny[1] : nd->maxy[1], ray.nz ? nd->minz[1] : nd->maxz[1], ray, t1);
+            const bool h2 = slab_test(ray.nx ? nd->maxx[2] : nd->minx[2], ray.ny ? nd->maxy[2] : nd->miny[2], ray.nz ? nd->maxz[2] : nd->minz[2],
+                                      ray.nx ? nd->minx[2] : nd->maxx[2], ray.ny ? nd->miny[2] : nd->maxy[2], ray.nz ? nd->minz[2] : nd->maxz[2], ray, t2);
+            const bool h3 = slab_test(ray.nx ? nd->maxx[3] : nd->minx[3], ray.ny ? nd->maxy[3] : nd->miny[3], ray.nz ? nd->maxz[3] : nd->minz[3],
+                                      ray.nx ? nd->minx[3] : nd->maxx[3], ray.ny ? nd->miny[3] : nd->maxy[3], ray.nz ? nd->minz[3] : nd->maxz[3], ray, t3);
+            uint32_t r0 = nd->ref[0], r1 = nd->ref[1], r2 = nd->ref[2], r3 = nd->ref[3];
+            // a child that is missed, entered beyond the limit, or absent sorts last with distance +inf
+            t0 = (h0 && !(t0 > limit)) ? t0 : INF;
+            t1 = (h1 && !(t1 > limit)) ? t1 : INF;
+            t2 = (h2 && !(t2 > limit)) ? t2 : INF;
+            t3 = (h3 && !(t3 > limit)) ? t3 : INF;
+            if (MODE != TRAV_ANY) {
+                // nearest first (a shadow walk does not care about the order)
+                RT_CSWAP(t0, r0, t1, r1); RT_CSWAP(t2, r2, t3, r3);
+                RT_CSWAP(t0, r0, t2, r2); RT_CSWAP(t1, r1, t3, r3);
+                RT_CSWAP(t1, r1, t2, r2);
+                if (t3 < INF) RT_STACK_PUSH(r3, t3);
+                if (t2 < INF) RT_STACK_PUSH(r2, t2);
+                if (t1 < INF) RT_STACK_PUSH(r1, t1);
+                cur = t0 < INF ? r0 : RT_POP;
+            } else {
+                cur = RT_POP;
+                float tc = INF;
+                if (t3 < INF) { cur = r3; tc = t3; }
+                if (t2 < INF) { if (cur != RT_POP) RT_STACK_PUSH(cur, tc); cur = r2; tc = t2; }
+                if (t1 < INF) { if (cur != RT_POP) RT_STACK_PUSH(cur, tc); cur = r1; tc = t1; }
+                if (t0 < INF) { if (cur != RT_POP) RT_STACK_PUSH(cur, tc); cur = r0; tc = t0; }
             }
-            if (cur == POP) break;
+            if (cur == RT_POP) {
+                while (sp > 0) {
+                    uint2 e;
+                    RT_STACK_POP(e);
+                    if (!(__uint_as_float(e.y) > limit)) { cur = e.x; break; }
+                }
+            }
+        }
+        if (cur == RT_POP) break;
+        // ---- one leaf: its triangles, exact f64 (mesh.rs:25-59)
+        uint32_t rank = cur & ~RT_LEAF_BIT;
+        while (true) {
+            const TriData T = tri_load(&tris[rank]);
+            const uint32_t last = T.last;
+            double t; float u, v;
+            vc.tris++;
+#ifdef RT_EXP_NOTRI
+            if (MODE != TRAV_ANY)
+#endif
+            if (tri_test(T, ray, t, u, v)) {
+                if (MODE == TRAV_ANY) {
+                    if (t <= bound) return true;
+                } else if (MODE == TRAV_CLOSEST) {
+                    if (t < mh.t0 || (t == mh.t0 && rank < mh.r0)) {
+                        mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v; mh.n = 1;
+                        limit = __double2float_ru(t);
+                    }
+                } else {
+                    if (mh.n == 0 || t < mh.t0 || (t == mh.t0 && rank < mh.r0)) {
+                        if (mh.n >= 1) { mh.t1 = mh.t0; mh.n = 2; } else mh.n = 1;
+                        mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v;
+                    } else if (mh.n == 1 || t < mh.t1) { mh.t1 = t; mh.n = 2; }
+                    if (mh.n == 2) limit = __double2float_ru(mh.t1);
+                }
+            }
+            if (last) break;
+            ++rank;
+        }
+        cur = RT_POP;
+        while (sp > 0) {
+            uint2 e;
+            RT_STACK_POP(e);
+            if (!(__uint_as_float(e.y) > limit)) { cur = e.x; break; }
         }
     }
     return mh.n > 0;

@@ -12,19 +12,21 @@
 
 struct D3 { double x, y, z; };
 
-// One inner node of a mesh's top-down BVH (acceleration.rs:407-417), re-emitted
-// compactly: a single 64-byte fetch (four 16-byte loads) carries BOTH children's
-// boxes and references, so a visit tests the two boxes it needs next without
-// touching the children themselves.  The boxes are f32, rounded OUTWARD from the
-// reference's f64 slab bounds (centroid -+ size, acceleration.rs:76,135): they
-// are used for culling only -- a box test that passes in the reference passes
-// here -- while every triangle test stays f64 and exact.
+// One inner node of the device BVH: the reference's binary top-down tree (acceleration.rs:407-417) re-emitted
+// four wide -- each node adopts its grandchildren -- so that a ray makes about half as many dependent node
+// fetches.  One 128-byte record carries the boxes and references of all (up to) four children, plane by
+// plane (min x of the 4 children, min y, ...), so a visit is seven 16-byte loads and tests the four boxes
+// without touching the children themselves.  The boxes are f32, rounded OUTWARD from the reference's f64
+// slab bounds (centroid -+ size, acceleration.rs:76,135): they are used for culling only -- a box test that
+// passes in the reference passes here -- while every triangle test stays f64 and exact.  Leaves keep the
+// reference's contents and order.
 #define RT_LEAF_BIT 0x80000000u
+#define RT_NO_CHILD 0xFFFFFFFFu
 struct __attribute__((aligned(16))) DNode {
-    float lmin[3], lmax[3];   // child a
-    float rmin[3], rmax[3];   // child b
-    uint32_t lref, rref;      // inner child: node index; leaf child: RT_LEAF_BIT | first triangle (leaf order)
-    uint32_t pad[2];
+    float minx[4], miny[4], minz[4];
+    float maxx[4], maxy[4], maxz[4];
+    uint32_t ref[4];          // inner child: node index; leaf child: RT_LEAF_BIT | first triangle (leaf order); RT_NO_CHILD: empty slot
+    uint32_t pad[4];
 };
 
 // One triangle in leaf order (the order mesh.rs:326-345 gathers candidates):
@@ -105,9 +107,14 @@ struct DLevel {
 
 enum { NF_DONE = 1, NF_TRANSPARENT = 2, NF_T_REFLECT = 4, NF_REFLECT = 8, NF_EMISSIVE = 16 };
 
+// Frame counters.  The two allocation cursors take one atomic per workgroup; the statistics are spread over
+// RT_SHARDS cache lines (a workgroup adds to shard blockIdx % RT_SHARDS) because thousands of adds to ONE word
+// serialise at about 12 ns each and would cost milliseconds per frame.  The host sums the shards.
+#define RT_SHARDS 64
+struct DShard { unsigned long long rays_reflect, rays_transmit, rays_shadow, nodes_visited, tris_tested, pad[11]; };   // 128 B
 struct DCounters {
-    unsigned long long rays_primary, rays_reflect, rays_transmit, rays_shadow;
     unsigned long long next_count;   // rays appended to the next level
-    unsigned long long hit_count;    // rays of the current level that hit something (length of the hit list)
-    unsigned long long nodes_visited, tris_tested;   // instrumented kernel variants only
+    unsigned long long hit_count;    // lit hits of the current level (length of the k_shadow work list)
+    unsigned long long pad[14];
+    DShard shard[RT_SHARDS];
 };

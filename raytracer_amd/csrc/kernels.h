@@ -15,6 +15,7 @@
 //             already-quantised colours and truncates to 8 bits itself.
 #pragma once
 #include "dev_rt.h"
+#include "dev_packet.h"
 
 #define RT_BLOCK RT_BLOCK_DIM
 #define RT_INACTIVE 0xFFFFFFFEu   // padding slot of an edge tile
@@ -29,8 +30,10 @@ DEV bool slot_pixel(const ShardMap& m, int32_t vw, int32_t vh, uint32_t slot, in
     uint64_t gid = (uint64_t)k * m.n_shards + m.shard;
     if (gid >= m.n_tiles) return false;
     uint32_t tx = (uint32_t)(gid % m.tiles_x), ty = (uint32_t)(gid / m.tiles_x);
-    x = (int32_t)(tx * 16u + (j & 15u));
-    y = (int32_t)(ty * 16u + (j >> 4));
+    // the 64 slots of one wave cover an 8x8 pixel block (a compact ray packet); four blocks make the tile
+    const uint32_t sub = j >> 6, w = j & 63u;
+    x = (int32_t)(tx * 16u + (sub & 1u) * 8u + (w & 7u));
+    y = (int32_t)(ty * 16u + (sub >> 1) * 8u + (w >> 3));
     return x < vw && y < vh;
 }
 
@@ -60,88 +63,133 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(const DScene* Sp, DLevel L
 DEV uint32_t lane_id() { return __lane_id(); }
 DEV unsigned long long lanes_below() { return (1ull << lane_id()) - 1ull; }
 
-// Appends one slot per flagged lane of the wave; one atomic per wave.
-DEV uint32_t wave_append(bool want, unsigned long long* counter) {
-    unsigned long long mask = __ballot(want);
-    uint32_t total = (uint32_t)__popcll(mask);
-    uint32_t base = 0;
-    if (total) {
-        int leader = __ffsll((long long)mask) - 1;
-        if ((int)lane_id() == leader) base = (uint32_t)atomicAdd(counter, (unsigned long long)total);
-        base = __shfl(base, leader);
+#define RT_WAVES (RT_BLOCK / 64)
+
+// Workgroup-wide append: every thread of the block calls it; flagged lanes get consecutive slots from *cursor.
+// One atomic per workgroup.  (Two flags at once: all `a` slots of the block come first, then all `b` slots.)
+DEV void block_append2(bool a, bool b, unsigned long long* cursor, uint32_t& slot_a, uint32_t& slot_b) {
+    __shared__ uint32_t s_cnt[2][RT_WAVES];
+    __shared__ uint32_t s_base;
+    const unsigned long long ma = __ballot(a), mb = __ballot(b);
+    const uint32_t w = threadIdx.x >> 6;
+    if (lane_id() == 0) { s_cnt[0][w] = (uint32_t)__popcll(ma); s_cnt[1][w] = (uint32_t)__popcll(mb); }
+    __syncthreads();
+    uint32_t before_a = 0, before_b = 0, tot_a = 0, tot_b = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < RT_WAVES; k++) {
+        const uint32_t ca = s_cnt[0][k], cb = s_cnt[1][k];
+        if (k < w) { before_a += ca; before_b += cb; }
+        tot_a += ca; tot_b += cb;
     }
-    return base + (uint32_t)__popcll(mask & lanes_below());
+    if (threadIdx.x == 0) s_base = (tot_a + tot_b) ? (uint32_t)atomicAdd(cursor, (unsigned long long)(tot_a + tot_b)) : 0u;
+    __syncthreads();
+    const uint32_t base = s_base;
+    slot_a = base + before_a + (uint32_t)__popcll(ma & lanes_below());
+    slot_b = base + tot_a + before_b + (uint32_t)__popcll(mb & lanes_below());
+    __syncthreads();   // s_cnt / s_base may be reused by the next call
 }
-DEV void wave_count(uint32_t v, unsigned long long* counter) {
-    // sum v over the wave, one atomic
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if (lane_id() == 0 && v) atomicAdd(counter, (unsigned long long)v);
+DEV uint32_t block_append(bool a, unsigned long long* cursor) {
+    uint32_t sa, sb;
+    block_append2(a, false, cursor, sa, sb);
+    return sa;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, uint32_t n, uint32_t* hitlist, DCounters* C) {
+// Workgroup-wide sum of up to three small per-thread counts, added to this workgroup's statistics shard.
+DEV void block_count3(uint32_t v0, uint32_t v1, uint32_t v2, unsigned long long* c0, unsigned long long* c1, unsigned long long* c2) {
+    __shared__ uint32_t s_red[3][RT_WAVES];
+    for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off); v1 += __shfl_down(v1, off); v2 += __shfl_down(v2, off); }
+    const uint32_t w = threadIdx.x >> 6;
+    if (lane_id() == 0) { s_red[0][w] = v0; s_red[1][w] = v1; s_red[2][w] = v2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t0 = 0, t1 = 0, t2 = 0;
+        for (uint32_t k = 0; k < RT_WAVES; k++) { t0 += s_red[0][k]; t1 += s_red[1][k]; t2 += s_red[2][k]; }
+        if (t0 && c0) atomicAdd(c0, (unsigned long long)t0);
+        if (t1 && c1) atomicAdd(c1, (unsigned long long)t1);
+        if (t2 && c2) atomicAdd(c2, (unsigned long long)t2);
+    }
+    __syncthreads();
+}
+DEV DShard* my_shard(DCounters* C) { return &C->shard[(blockIdx.x + blockIdx.y * 7u) % RT_SHARDS]; }
+
+// Closest hit of every ray of the level.  Rays whose hit will be lit are appended (in wave order) to the work list
+// of k_shadow together with what a shadow ray needs from the hit: the hit point and the offset origin
+// vnear + normal * EPSILON (sun.rs:88, point.rs:90), stored plane by plane: hs[k * stride + slot], k = 0..5.
+template <bool COUNT, bool PACKET>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, uint32_t n, uint32_t* hitlist, double* hs, uint32_t stride, DCounters* C) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     const DScene& S = *Sp;
-    bool hit = false;
+    bool lit = false;
+    D3 vnear = d3(0., 0., 0.), so = d3(0., 0., 0.);
     Visits vc; vc.nodes = 0; vc.tris = 0;
-    if (i < n && L.hit_obj[i] != RT_INACTIVE) {
-        Ray ray = load_ray(L, i);
+    const bool active = i < n && L.hit_obj[i] != RT_INACTIVE;
+    const uint32_t ii = i < n ? i : 0;
+    if (PACKET || active) {
+        // PACKET: the wave's rays are coherent (primary rays of an 8x8 pixel block) and walk the BVH together
+        Ray ray = load_ray(L, ii);
         Closest c;
-        hit = cast_closest(S, ray, c, vc);
-        L.hit_obj[i] = c.obj; L.hit_prim[i] = c.rank;
-        L.hit_t[i] = c.t; L.hit_t2[i] = c.t2; L.hit_u[i] = c.u; L.hit_v[i] = c.v;
+        const bool hit = PACKET ? cast_closest_packet(S, ray, active, c, vc) : cast_closest(S, ray, c, vc);
+        if (active) {
+            L.hit_obj[i] = c.obj; L.hit_prim[i] = c.rank;
+            L.hit_t[i] = c.t; L.hit_t2[i] = c.t2; L.hit_u[i] = c.u; L.hit_v[i] = c.v;
+        }
+        if (active && hit && S.n_lights != 0) {
+            const RT_GLOBAL DObject* op = gptr(S.objects) + c.obj;
+            if (!(gptr(S.materials)[op->material].emissivity == 1.)) {      // scene.rs:105-107: fully emissive = no lighting
+                Hit h;
+                closest_hit_fill(S, ray, c.obj, c.rank, c.t, c.t2, c.u, c.v, h);
+                vnear = h.vnear;
+                so = h.vnear + h.normal * RT_EPSILON;
+                lit = true;
+            }
+        }
     }
-    // rays that hit something, in wave order: the work list of k_shadow
-    uint32_t slot = wave_append(hit, &C->hit_count);
-    if (hit) hitlist[slot] = i;
-    if (COUNT) { wave_count(vc.nodes, &C->nodes_visited); wave_count(vc.tris, &C->tris_tested); }
+    const uint32_t slot = block_append(lit, &C->hit_count);
+    if (lit) {
+        hitlist[slot] = i;
+        hs[slot] = vnear.x; hs[(size_t)stride + slot] = vnear.y; hs[2 * (size_t)stride + slot] = vnear.z;
+        hs[3 * (size_t)stride + slot] = so.x; hs[4 * (size_t)stride + slot] = so.y; hs[5 * (size_t)stride + slot] = so.z;
+    }
+    if (COUNT) { DShard* sh = my_shard(C); block_count3(vc.nodes, vc.tris, 0, &sh->nodes_visited, &sh->tris_tested, nullptr); }
 }
 
-// The shadow ray of one light at one hit (sun.rs:87-89, point.rs:68-76,89-91); false when the light casts none
-// there (sun without shadows; point light beyond max_distance, which contributes LightShading::default()).
-DEV bool shadow_ray_for(const DLight& Lt, const Hit& hit, Ray& sr, bool& limited, double& dist) {
-    if (Lt.kind == 0) {
-        if (!Lt.shadows) return false;
-        sr = ray_new(hit.vnear + hit.normal * RT_EPSILON, -ld3(Lt.v));
-        limited = false; dist = 0.;
-        return true;
-    }
-    D3 lvec = ld3(Lt.v) - hit.vnear;
-    dist = magnitude(lvec);
-    if (dist > Lt.max_distance) return false;
-    lvec = lvec / dist;
-    sr = ray_new(hit.vnear + hit.normal * RT_EPSILON, lvec);
-    limited = true;
-    return true;
-}
-
-// One thread per (ray that hit, light): the light's shadow cast.  Lanes of a wave share the light and walk
-// neighbouring hit points, so their shadow rays are coherent.  occ[light * stride + ray] = 1 when shadowed.
+// One thread per (lit hit, light): the light's shadow cast (sun.rs:87-94, point.rs:68-76,89-99).  Lanes of a wave
+// share the light and walk neighbouring hit points, so their shadow rays are coherent.  A light casts no ray
+// where it has shadows off (sun) or lies beyond max_distance (point: LightShading::default()).
+// occ[light * stride + ray] = 1 when shadowed.
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow(const DScene* Sp, DLevel L, const uint32_t* hitlist, uint8_t* occ, uint32_t stride, DCounters* C) {
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride, DCounters* C) {
     const uint32_t h = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t li = blockIdx.y;
     const DScene& S = *Sp;
     Visits vc; vc.nodes = 0; vc.tris = 0;
     uint32_t cast = 0;
-    if (h < (uint32_t)C->hit_count) {
-        const uint32_t i = hitlist[h];
-        const uint32_t obj = L.hit_obj[i];
-        const DMaterial& mat = S.materials[S.objects[obj].material];
-        if (!(mat.emissivity == 1.)) {                                  // scene.rs:105-107: no lighting at all
-            const DLight& Lt = S.lights[li];
-            Ray ray = load_ray(L, i);
-            Hit hit;
-            closest_hit_fill(S, ray, obj, L.hit_prim[i], L.hit_t[i], L.hit_t2[i], L.hit_u[i], L.hit_v[i], hit);
-            Ray sr; bool limited; double dist;
-            if (shadow_ray_for(Lt, hit, sr, limited, dist)) {
-                cast = 1;
-                occ[(size_t)li * stride + i] = cast_any(S, sr, limited, dist, vc) ? 1 : 0;
-            }
+    {
+        const bool have = h < (uint32_t)C->hit_count;
+        const uint32_t hh = have ? h : 0;
+        const RT_GLOBAL DLight* Lt = gptr(S.lights) + li;
+        const D3 vnear = d3(hs[hh], hs[(size_t)stride + hh], hs[2 * (size_t)stride + hh]);
+        const D3 so = d3(hs[3 * (size_t)stride + hh], hs[4 * (size_t)stride + hh], hs[5 * (size_t)stride + hh]);
+        const D3 lv = d3(Lt->v[0], Lt->v[1], Lt->v[2]);
+        bool limited = false; double dist = 0.; D3 dir;
+        if (Lt->kind == 0) {
+            cast = Lt->shadows ? 1u : 0u;
+            dir = -lv;
+        } else {
+            D3 lvec = lv - vnear;
+            dist = magnitude(lvec);
+            cast = dist > Lt->max_distance ? 0u : 1u;
+            dir = lvec / dist;
+            limited = true;
         }
+        if (!have) cast = 0;
+        // the wave's shadow rays leave neighbouring hit points towards one light: walked as a packet
+        const bool blocked = cast_any_packet(S, ray_new(so, dir), cast != 0, limited, dist, vc);
+        if (cast) occ[(size_t)li * stride + hitlist[hh]] = blocked ? 1 : 0;
     }
-    wave_count(cast, &C->rays_shadow);
-    if (COUNT) { wave_count(vc.nodes, &C->nodes_visited); wave_count(vc.tris, &C->tris_tested); }
+    DShard* sh = my_shard(C);
+    if (COUNT) block_count3(cast, vc.nodes, vc.tris, &sh->rays_shadow, &sh->nodes_visited, &sh->tris_tested);
+    else block_count3(cast, 0, 0, &sh->rays_shadow, nullptr, nullptr);
 }
 
 // One light's contribution (lighting/sun.rs:72-97, point.rs:66-105) given its shadow cast's result
@@ -268,8 +316,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, 
         }
     }
     // append the children to the next level (whole wave takes part)
-    uint32_t s0 = wave_append(want0, &C->next_count);
-    uint32_t s1 = wave_append(want1, &C->next_count);
+    uint32_t s0, s1;
+    block_append2(want0, want1, &C->next_count, s0, s1);
     if (want0 && s0 >= next_cap) want0 = false;
     if (want1 && s1 >= next_cap) want1 = false;
     if (active && !((L.base_flags[i] >> 24) & NF_DONE)) {
@@ -278,9 +326,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, 
     }
     if (want0) { store_ray(N, s0, c0o, c0d); N.hit_obj[s0] = RT_NONE; }
     if (want1) { store_ray(N, s1, c1o, c1d); N.hit_obj[s1] = RT_NONE; }
-    wave_count(want0 ? 1u : 0u, &C->rays_transmit);
-    wave_count(want1 ? 1u : 0u, &C->rays_reflect);
-    if (COUNT) { wave_count(vc.nodes, &C->nodes_visited); wave_count(vc.tris, &C->tris_tested); }
+    DShard* sh = my_shard(C);
+    block_count3(want0 ? 1u : 0u, want1 ? 1u : 0u, 0, &sh->rays_transmit, &sh->rays_reflect, nullptr);
+    if (COUNT) block_count3(vc.nodes, vc.tris, 0, &sh->nodes_visited, &sh->tris_tested, nullptr);
 }
 
 // Folds one level into its parents' view: scene.rs:176-205 on the children's

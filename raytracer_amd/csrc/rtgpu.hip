@@ -44,6 +44,7 @@ struct rt_ctx {
     void* d_ids2 = nullptr; size_t d_ids2_cap = 0;    // row-major ids
     void* d_hitlist = nullptr; size_t d_hitlist_cap = 0;   // rays of the current level that hit something
     void* d_occ = nullptr; size_t d_occ_cap = 0;      // shadow results [light][ray] of the current level
+    void* d_hs = nullptr; size_t d_hs_cap = 0;        // hit point + shadow-ray origin of every lit hit, 6 planes of doubles
     bool count_visits = false;                        // RTGPU_COUNT_VISITS=1: instrumented kernels
     uint32_t n_lights = 0;
     hipEvent_t ev[8];
@@ -164,25 +165,62 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
             bmin[k] = flo; bmax[k] = fhi;
         }
     };
-    auto ref_of = [&](uint32_t i) -> uint32_t {
+    // Collapse to four-wide nodes: a node's children are its two reference children, the larger (by surface
+    // area) inner ones replaced by their own two children until four slots are used.  Children keep the
+    // reference's left-to-right order.  Device nodes are numbered in depth-first order of this wider tree.
+    auto area_of = [&](uint32_t i) {
         const rt_bvh_node& nd = m.nodes[i];
-        return nd.count == 0 ? inner_id[i] : (RT_LEAF_BIT | nd.right_or_first);
+        const double x = nd.max[0] - nd.min[0], y = nd.max[1] - nd.min[1], z = nd.max[2] - nd.min[2];
+        return 2. * x * y + 2. * x * z + 2. * y * z;
     };
-    std::vector<DNode> nodes(n_inner);
+    std::vector<DNode> nodes;
+    nodes.reserve(n_inner / 2 + 1);
     std::vector<uint8_t> last(m.n_prims, 0);
-    for (uint32_t i = 0; i < NN; i++) {
-        if (!seen[i]) continue;
-        const rt_bvh_node& nd = m.nodes[i];
-        if (nd.count == 0) {
-            DNode& dn = nodes[inner_id[i]];
+    for (uint32_t i = 0; i < NN; i++)
+        if (seen[i] && m.nodes[i].count != 0) last[m.nodes[i].right_or_first + m.nodes[i].count - 1] = 1;
+    if (m.nodes[0].count == 0) {
+        std::vector<std::pair<uint32_t, uint32_t>> work;   // (reference node, device node index)
+        nodes.emplace_back();
+        work.push_back({0u, 0u});
+        while (!work.empty()) {
+            auto [ri, di] = work.back(); work.pop_back();
+            uint32_t kids[4]; int nk = 2;
+            kids[0] = ri + 1; kids[1] = m.nodes[ri].right_or_first;
+            while (nk < 4) {
+                int best = -1; double ba = -1.;
+                for (int k = 0; k < nk; k++)
+                    if (m.nodes[kids[k]].count == 0) { const double a = area_of(kids[k]); if (best < 0 || a > ba) { best = k; ba = a; } }
+                if (best < 0) break;
+                const uint32_t e = kids[best];
+                for (int k = nk; k > best + 1; k--) kids[k] = kids[k - 1];
+                kids[best] = e + 1; kids[best + 1] = m.nodes[e].right_or_first;
+                nk++;
+            }
+            DNode dn;
             std::memset(&dn, 0, sizeof(dn));
-            box_of(i + 1, dn.lmin, dn.lmax);
-            box_of(nd.right_or_first, dn.rmin, dn.rmax);
-            dn.lref = ref_of(i + 1); dn.rref = ref_of(nd.right_or_first);
-        } else {
-            last[nd.right_or_first + nd.count - 1] = 1;
+            uint32_t child_dev[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 4; k++) {
+                if (k >= nk) {
+                    // empty slot: a box no ray enters
+                    dn.minx[k] = dn.miny[k] = dn.minz[k] = INFINITY;
+                    dn.maxx[k] = dn.maxy[k] = dn.maxz[k] = -INFINITY;
+                    dn.ref[k] = RT_NO_CHILD;
+                    continue;
+                }
+                float bmin[3], bmax[3];
+                box_of(kids[k], bmin, bmax);
+                dn.minx[k] = bmin[0]; dn.miny[k] = bmin[1]; dn.minz[k] = bmin[2];
+                dn.maxx[k] = bmax[0]; dn.maxy[k] = bmax[1]; dn.maxz[k] = bmax[2];
+                const rt_bvh_node& kn = m.nodes[kids[k]];
+                if (kn.count != 0) dn.ref[k] = RT_LEAF_BIT | kn.right_or_first;
+                else { child_dev[k] = (uint32_t)nodes.size(); nodes.emplace_back(); dn.ref[k] = child_dev[k]; }
+            }
+            nodes[di] = dn;
+            for (int k = nk - 1; k >= 0; k--)
+                if (m.nodes[kids[k]].count == 0) work.push_back({kids[k], child_dev[k]});
         }
     }
+    n_inner = (uint32_t)nodes.size();
     std::vector<DTri> tris(m.n_prims);
     for (uint32_t r = 0; r < m.n_prims; r++) {
         const uint32_t t = m.prim_indices[r];
@@ -301,18 +339,26 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
         if ((rc = ensure_level(c, depth + 1, next_cap)) != RT_OK) return rc;
         if ((rc = ensure_buf(c, &c->d_hitlist, &c->d_hitlist_cap, (size_t)n * 4)) != RT_OK) return rc;
         if (c->n_lights && (rc = ensure_buf(c, &c->d_occ, &c->d_occ_cap, (size_t)n * c->n_lights)) != RT_OK) return rc;
+        if ((rc = ensure_buf(c, &c->d_hs, &c->d_hs_cap, (size_t)n * 48)) != RT_OK) return rc;
+        double* hs = static_cast<double*>(c->d_hs);
         uint32_t* hitlist = static_cast<uint32_t*>(c->d_hitlist);
         uint8_t* occ = static_cast<uint8_t*>(c->d_occ);
         const dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
         HIP_TRY(c, hipEventRecord(c->ev[1], s));
-        if (c->count_visits) hipLaunchKernelGGL(k_trace<true>, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, c->dcounters);
-        else hipLaunchKernelGGL(k_trace<false>, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, c->dcounters);
+        // depth 0: primary rays, 8x8 pixel blocks per wave -> coherent packets; deeper rays are walked lane by lane
+        if (depth == 0) {
+            if (c->count_visits) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters);
+            else hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters);
+        } else {
+            if (c->count_visits) hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters);
+            else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters);
+        }
         HIP_TRY(c, hipEventRecord(c->ev[2], s));
         if (c->n_lights) {
             // sized for the worst case (every ray hit); threads past the hit count leave at once
             const dim3 sgrid((n + RT_BLOCK - 1) / RT_BLOCK, c->n_lights);
-            if (c->count_visits) hipLaunchKernelGGL(k_shadow<true>, sgrid, block, 0, s, c->dscene, c->levels[depth].lv, hitlist, occ, n, c->dcounters);
-            else hipLaunchKernelGGL(k_shadow<false>, sgrid, block, 0, s, c->dscene, c->levels[depth].lv, hitlist, occ, n, c->dcounters);
+            if (c->count_visits) hipLaunchKernelGGL(k_shadow<true>, sgrid, block, 0, s, c->dscene, hitlist, hs, occ, n, c->dcounters);
+            else hipLaunchKernelGGL(k_shadow<false>, sgrid, block, 0, s, c->dscene, hitlist, hs, occ, n, c->dcounters);
             n_sd++;
         }
         HIP_TRY(c, hipEventRecord(c->ev[6], s));
@@ -352,11 +398,12 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
     (void)hipEventElapsedTime(&ms_resolve, c->ev[4], c->ev[5]);
     float ms_all = 0.f;
     (void)hipEventElapsedTime(&ms_all, c->ev[0], c->ev[5]);
-    stats.rays_reflect = c->hcounters->rays_reflect;
-    stats.rays_transmit = c->hcounters->rays_transmit;
-    stats.rays_shadow = c->hcounters->rays_shadow;
+    for (int k = 0; k < RT_SHARDS; k++) {
+        const DShard& sh = c->hcounters->shard[k];
+        stats.rays_reflect += sh.rays_reflect; stats.rays_transmit += sh.rays_transmit; stats.rays_shadow += sh.rays_shadow;
+        stats.nodes_visited += sh.nodes_visited; stats.tris_tested += sh.tris_tested;
+    }
     stats.ms_render = ms_all; stats.ms_trace = ms_trace; stats.ms_shadow = ms_shadow; stats.ms_shade = ms_shade; stats.ms_resolve = ms_resolve;
-    stats.nodes_visited = c->hcounters->nodes_visited; stats.tris_tested = c->hcounters->tris_tested;
     stats.launches_trace = n_tr; stats.launches_shadow = n_sd; stats.launches_shade = n_sh;
     stats.ms_upload = c->ms_upload;
     stats.device_bytes = c->scene_bytes + c->work_bytes;
@@ -408,6 +455,7 @@ void rt_ctx_destroy(rt_ctx* c) {
     if (c->d_ids2) (void)hipFree(c->d_ids2);
     if (c->d_hitlist) (void)hipFree(c->d_hitlist);
     if (c->d_occ) (void)hipFree(c->d_occ);
+    if (c->d_hs) (void)hipFree(c->d_hs);
     if (c->dscene) (void)hipFree(c->dscene);
     if (c->dcounters) (void)hipFree(c->dcounters);
     if (c->hcounters) (void)hipHostFree(c->hcounters);

@@ -35,8 +35,10 @@ def shard_pixel_indices(vw, vh, shard, n_shards):
     j = np.arange(slots, dtype=np.int64) & 255
     gid = k * n_shards + shard
     tiles_x = (vw + TILE - 1) // TILE
-    x = (gid % tiles_x) * TILE + (j & 15)
-    y = (gid // tiles_x) * TILE + (j >> 4)
+    # the 64 slots of one wave cover an 8x8 pixel block; four blocks make the 16x16 tile
+    sub, w = j >> 6, j & 63
+    x = (gid % tiles_x) * TILE + (sub & 1) * 8 + (w & 7)
+    y = (gid // tiles_x) * TILE + (sub >> 1) * 8 + (w >> 3)
     ok = (x < vw) & (y < vh)
     return np.where(ok, y * vw + x, -1)
 
