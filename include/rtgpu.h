@@ -170,6 +170,9 @@ typedef struct rt_stats {
      * created with RTGPU_COUNT_VISITS=1 in the environment (instrumented kernel
      * variants, slower); 0 otherwise. */
     uint64_t nodes_visited, tris_tested;
+    /* the same for the wave-coherent packet walks, counted once per wave (a wave visits a node / tests a
+     * triangle when any of its 64 rays needs it) */
+    uint64_t wave_nodes, wave_tris;
     uint32_t launches_trace, launches_shadow, launches_shade, _pad;   /* kernel launches of the last frame */
 } rt_stats;
 

@@ -28,7 +28,7 @@ class RtStats(C.Structure):
         ("ms_upload", C.c_double), ("ms_render", C.c_double), ("ms_total", C.c_double),
         ("ms_trace", C.c_double), ("ms_shadow", C.c_double), ("ms_shade", C.c_double), ("ms_resolve", C.c_double),
         ("device_bytes", C.c_uint64),
-        ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
+        ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("wave_nodes", C.c_uint64), ("wave_tris", C.c_uint64),
         ("launches_trace", C.c_uint32), ("launches_shadow", C.c_uint32), ("launches_shade", C.c_uint32), ("_pad", C.c_uint32),
     ]
 

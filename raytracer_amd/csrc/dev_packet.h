@@ -49,7 +49,7 @@ DEV TriData load_utri(const DTri* tris, uint32_t rank) {
 }
 
 // slab test of this lane's ray against child k of a uniform node
-#define RT_CHILD_TEST(n, k, ray, tn)                                                                                      \
+#define RT_CHILD_TEST(n, k, tn)                                                                                           \
     slab_test((ray).nx ? asf((n).maxx[k]) : asf((n).minx[k]), (ray).ny ? asf((n).maxy[k]) : asf((n).miny[k]),            \
               (ray).nz ? asf((n).maxz[k]) : asf((n).minz[k]), (ray).nx ? asf((n).minx[k]) : asf((n).maxx[k]),            \
               (ray).ny ? asf((n).miny[k]) : asf((n).maxy[k]), (ray).nz ? asf((n).minz[k]) : asf((n).maxz[k]), (ray), (tn))
@@ -108,6 +108,7 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
                 const TriData T = load_utri(tris, rank);
                 double t; float u, v;
                 if (in) vc.tris++;
+                vc.wtris++;
                 const bool hit = in && tri_test(T, ray, t, u, v);
                 if (MODE == TRAV_ANY) {
                     if (hit && t <= bound) found = true;
@@ -130,9 +131,10 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
             const UNode n = load_unode(nodes, cur);
             const bool in = lane_in(curmask & alive);
             if (in) vc.nodes++;
+            vc.wnodes++;
             float t0, t1, t2, t3;
-            const bool h0 = RT_CHILD_TEST(n, 0, ray, t0), h1 = RT_CHILD_TEST(n, 1, ray, t1);
-            const bool h2 = RT_CHILD_TEST(n, 2, ray, t2), h3 = RT_CHILD_TEST(n, 3, ray, t3);
+            const bool h0 = RT_CHILD_TEST(n, 0, t0), h1 = RT_CHILD_TEST(n, 1, t1);
+            const bool h2 = RT_CHILD_TEST(n, 2, t2), h3 = RT_CHILD_TEST(n, 3, t3);
             unsigned long long m0 = __ballot(in && h0 && !(t0 > limit)), m1 = __ballot(in && h1 && !(t1 > limit));
             unsigned long long m2 = __ballot(in && h2 && !(t2 > limit)), m3 = __ballot(in && h3 && !(t3 > limit));
             uint32_t r0 = n.ref[0], r1 = n.ref[1], r2 = n.ref[2], r3 = n.ref[3];

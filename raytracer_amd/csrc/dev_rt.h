@@ -261,7 +261,7 @@ struct MeshHit { double t0, t1; uint32_t r0; float u, v; uint32_t n; };   // n =
 // Per-lane traversal context: the lane's stack column in LDS, and the work the traversal really did
 // (inner-node visits = two box tests each, triangle tests); only the instrumented kernel variants store the
 // counts, elsewhere the increments are dead code.
-struct Visits { uint32_t nodes, tris; };
+struct Visits { uint32_t nodes, tris; uint32_t wnodes, wtris; };   // per-lane counts; wave-level counts of the packet walk (same in every lane)
 
 // Traversal stack: (node reference, entry distance) pairs.  The first RT_LDS_STACK entries of every lane live
 // in LDS, laid out [entry][lane] so that a wave's push or pop touches consecutive 8-byte words (no bank
@@ -522,7 +522,7 @@ __device__ bool cast_any(const DScene& S, const Ray& ray, bool limited, double d
 __device__ void closest_hit_fill(const DScene& S, const Ray& ray, uint32_t obj, uint32_t rank, double t, double t2, float u, float v, Hit& h) {
     const RT_GLOBAL DObject* op = gptr(S.objects) + obj;
     if (op->kind == 3) mesh_hit_fill(S.meshes[op->payload], ray, rank, t, t2, u, v, h);
-    else { Visits none; none.nodes = 0; none.tris = 0; object_intersect(S, obj, ray, h, none); }   // never a mesh here
+    else { Visits none; none.nodes = 0; none.tris = 0; none.wnodes = 0; none.wtris = 0; object_intersect(S, obj, ray, h, none); }   // never a mesh here
 }
 
 // ---------------------------------------------------------------- material.rs:119-141

@@ -111,7 +111,7 @@ enum { NF_DONE = 1, NF_TRANSPARENT = 2, NF_T_REFLECT = 4, NF_REFLECT = 8, NF_EMI
 // RT_SHARDS cache lines (a workgroup adds to shard blockIdx % RT_SHARDS) because thousands of adds to ONE word
 // serialise at about 12 ns each and would cost milliseconds per frame.  The host sums the shards.
 #define RT_SHARDS 64
-struct DShard { unsigned long long rays_reflect, rays_transmit, rays_shadow, nodes_visited, tris_tested, pad[11]; };   // 128 B
+struct DShard { unsigned long long rays_reflect, rays_transmit, rays_shadow, nodes_visited, tris_tested, wave_nodes, wave_tris, pad[9]; };   // 128 B
 struct DCounters {
     unsigned long long next_count;   // rays appended to the next level
     unsigned long long hit_count;    // lit hits of the current level (length of the k_shadow work list)

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, 
     const DScene& S = *Sp;
     bool lit = false;
     D3 vnear = d3(0., 0., 0.), so = d3(0., 0., 0.);
-    Visits vc; vc.nodes = 0; vc.tris = 0;
+    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
     const bool active = i < n && L.hit_obj[i] != RT_INACTIVE;
     const uint32_t ii = i < n ? i : 0;
     if (PACKET || active) {
@@ -150,7 +150,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, 
         hs[slot] = vnear.x; hs[(size_t)stride + slot] = vnear.y; hs[2 * (size_t)stride + slot] = vnear.z;
         hs[3 * (size_t)stride + slot] = so.x; hs[4 * (size_t)stride + slot] = so.y; hs[5 * (size_t)stride + slot] = so.z;
     }
-    if (COUNT) { DShard* sh = my_shard(C); block_count3(vc.nodes, vc.tris, 0, &sh->nodes_visited, &sh->tris_tested, nullptr); }
+    if (COUNT) {
+        DShard* sh = my_shard(C);
+        block_count3(vc.nodes, vc.tris, 0, &sh->nodes_visited, &sh->tris_tested, nullptr);
+        block_count3(lane_id() == 0 ? vc.wnodes : 0, lane_id() == 0 ? vc.wtris : 0, 0, &sh->wave_nodes, &sh->wave_tris, nullptr);
+    }
 }
 
 // One thread per (lit hit, light): the light's shadow cast (sun.rs:87-94, point.rs:68-76,89-99).  Lanes of a wave
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(const DScene* Sp, const uin
     const uint32_t h = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t li = blockIdx.y;
     const DScene& S = *Sp;
-    Visits vc; vc.nodes = 0; vc.tris = 0;
+    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
     uint32_t cast = 0;
     {
         const bool have = h < (uint32_t)C->hit_count;
@@ -188,8 +192,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(const DScene* Sp, const uin
         if (cast) occ[(size_t)li * stride + hitlist[hh]] = blocked ? 1 : 0;
     }
     DShard* sh = my_shard(C);
-    if (COUNT) block_count3(cast, vc.nodes, vc.tris, &sh->rays_shadow, &sh->nodes_visited, &sh->tris_tested);
-    else block_count3(cast, 0, 0, &sh->rays_shadow, nullptr, nullptr);
+    if (COUNT) {
+        block_count3(cast, vc.nodes, vc.tris, &sh->rays_shadow, &sh->nodes_visited, &sh->tris_tested);
+        block_count3(lane_id() == 0 ? vc.wnodes : 0, lane_id() == 0 ? vc.wtris : 0, 0, &sh->wave_nodes, &sh->wave_tris, nullptr);
+    } else block_count3(cast, 0, 0, &sh->rays_shadow, nullptr, nullptr);
 }
 
 // One light's contribution (lighting/sun.rs:72-97, point.rs:66-105) given its shadow cast's result
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, 
         if (ids_out && depth == 0) { ids_out[2 * (size_t)i] = RT_NONE; ids_out[2 * (size_t)i + 1] = RT_NONE; }
         active = false;
     }
-    Visits vc; vc.nodes = 0; vc.tris = 0;
+    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
     bool want0 = false, want1 = false;
     D3 c0o = d3(0, 0, 0), c0d = d3(0, 0, 1), c1o = d3(0, 0, 0), c1d = d3(0, 0, 1);
 
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(const DScene* Sp, const doub
     bool any = false; uint32_t best = RT_NONE; Hit bh;
     for (uint32_t oi = 0; oi < S.n_objects; oi++) {
         Hit h;
-        Visits vc; vc.nodes = 0; vc.tris = 0;
+        Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
         if (object_intersect(S, oi, ray, h, vc) && (!any || h.near < bh.near)) { any = true; best = oi; bh = h; }
     }
     if (any) {

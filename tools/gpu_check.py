@@ -23,7 +23,7 @@ def check(name, s, sample=None):
         g_rgb, g_ids = rgb.reshape(-1, 3)[px], ids.reshape(-1, 2)[px]
     to = time.time() - t
     m = image_metrics(g_rgb, orgb)
-    print(f"{name}: {ctx.vw}x{ctx.vh} upload {tu*1e3:.0f} ms gpu {st.ms_render:.2f} ms (trace {st.ms_trace:.2f} shadow {st.ms_shadow:.2f} shade {st.ms_shade:.2f} resolve {st.ms_resolve:.2f}; visits nodes {st.nodes_visited} tris {st.tris_tested}) "
+    print(f"{name}: {ctx.vw}x{ctx.vh} upload {tu*1e3:.0f} ms gpu {st.ms_render:.2f} ms (trace {st.ms_trace:.2f} shadow {st.ms_shadow:.2f} shade {st.ms_shade:.2f} resolve {st.ms_resolve:.2f}; visits nodes {st.nodes_visited} tris {st.tris_tested} wave-nodes {st.wave_nodes} wave-tris {st.wave_tris}) "
           f"rays {st.rays} -> {st.rays / st.ms_render / 1e3:.1f} Mrays/s | oracle {to:.1f}s | exact {m['exact']:.6f} within1 {m['within1']:.6f} max {m['max_abs']} psnr {m['psnr']:.1f} ids {id_match(g_ids, oids):.6f}"
           + ("" if sample else f" | rays gpu {ray_counts(st)} cpu {ray_counts(ost)}"), flush=True)
     ctx.close()
