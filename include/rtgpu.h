@@ -174,6 +174,10 @@ typedef struct rt_stats {
      * triangle when any of its 64 rays needs it) */
     uint64_t wave_nodes, wave_tris;
     uint32_t launches_trace, launches_shadow, launches_shade, _pad;   /* kernel launches of the last frame */
+    /* rays whose walk exceeded its budget and was finished piecewise by the long-ray kernels */
+    uint64_t long_trace, long_shadow;
+    /* instrumented contexts only: the longest walk (inner nodes + triangle tests) of one lane / of one wave packet */
+    uint64_t max_lane_steps, max_wave_steps;
 } rt_stats;
 
 /* result of one probe ray (rt_cast_rays): the fields of object/mod.rs:18-36

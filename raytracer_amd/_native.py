@@ -30,6 +30,8 @@ class RtStats(C.Structure):
         ("device_bytes", C.c_uint64),
         ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("wave_nodes", C.c_uint64), ("wave_tris", C.c_uint64),
         ("launches_trace", C.c_uint32), ("launches_shadow", C.c_uint32), ("launches_shade", C.c_uint32), ("_pad", C.c_uint32),
+        ("long_trace", C.c_uint64), ("long_shadow", C.c_uint64),
+        ("max_lane_steps", C.c_uint64), ("max_wave_steps", C.c_uint64),
     ]
 
     @property

@@ -48,11 +48,44 @@ DEV TriData load_utri(const DTri* tris, uint32_t rank) {
     return t;
 }
 
+// Per-lane constants of the packet walk's box test.  The slab distance (b - o) * m is evaluated as
+// fma(b, m, c) with c = -(o * m) rounded to f32: one instruction per plane, one rounding of the result.  Against
+// the exact distance the value is off by at most 2^-24 |o m| (rounding of c) plus 2^-23 relative (rounding of m
+// and of the result).  The first is covered by moving c outward per plane (entry planes down, exit planes up),
+// the second by the relative slack after the reductions.  1/direction is clamped to +-1e30 so that an
+// axis-parallel ray gives no inf - inf.
+struct PRay { float mx, my, mz, cminx, cminy, cminz, cmaxx, cmaxy, cmaxz; };
+DEV void pray_axis(double o, double m, float& mf, float& cmin, float& cmax) {
+    mf = fminf(fmaxf((float)m, -1e30f), 1e30f);
+    const double om = o * (double)mf;
+    const float slack = (float)(fabs(om) * 1.2e-7);   // 2^-23 |o m|
+    const float lo = __double2float_rd(-om) - slack, hi = __double2float_ru(-om) + slack;
+    const bool pos = !(mf < 0.f);
+    cmin = pos ? lo : hi;   // the min plane is the entry plane when the ray runs in +axis direction
+    cmax = pos ? hi : lo;
+}
+DEV PRay pray_new(const Ray& r) {
+    PRay p;
+    pray_axis(r.o.x, r.m.x, p.mx, p.cminx, p.cmaxx);
+    pray_axis(r.o.y, r.m.y, p.my, p.cminy, p.cmaxy);
+    pray_axis(r.o.z, r.m.z, p.mz, p.cminz, p.cmaxz);
+    return p;
+}
+DEV bool pslab(float minx, float miny, float minz, float maxx, float maxy, float maxz, const PRay& p, float& tn_out) {
+    const float lx = fmaf(minx, p.mx, p.cminx), hx = fmaf(maxx, p.mx, p.cmaxx);
+    const float ly = fmaf(miny, p.my, p.cminy), hy = fmaf(maxy, p.my, p.cmaxy);
+    const float lz = fmaf(minz, p.mz, p.cminz), hz = fmaf(maxz, p.mz, p.cmaxz);
+    float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fminf(lz, hz));
+    float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fmaxf(lz, hz));
+    tn = fmaf(-fabsf(tn), 4.76837158203125e-07f, tn);   // 2^-21
+    tf = fmaf(fabsf(tf), 4.76837158203125e-07f, tf);
+    tn_out = tn;
+    return !(tn > tf || tf < 0.f);
+}
+
 // slab test of this lane's ray against child k of a uniform node
 #define RT_CHILD_TEST(n, k, tn)                                                                                           \
-    slab_test((ray).nx ? asf((n).maxx[k]) : asf((n).minx[k]), (ray).ny ? asf((n).maxy[k]) : asf((n).miny[k]),            \
-              (ray).nz ? asf((n).maxz[k]) : asf((n).minz[k]), (ray).nx ? asf((n).minx[k]) : asf((n).maxx[k]),            \
-              (ray).ny ? asf((n).miny[k]) : asf((n).maxy[k]), (ray).nz ? asf((n).minz[k]) : asf((n).maxz[k]), (ray), (tn))
+    pslab(asf((n).minx[k]), asf((n).miny[k]), asf((n).minz[k]), asf((n).maxx[k]), asf((n).maxy[k]), asf((n).maxz[k]), pr, (tn))
 
 // uniform compare-exchange on (key, ref, mask)
 #define RT_UCSWAP(ka, ra, ma, kb, rb, mb)                                     \
@@ -83,13 +116,19 @@ struct PStack {
 // MODE: TRAV_CLOSEST (nearest hit with t < bound, per lane) or TRAV_ANY (any hit with t <= bound, per lane).
 // Every lane of the wave must call this; `active` says whether the lane carries a ray.
 // TRAV_ANY returns true in the lanes whose ray is blocked.
+// budget: the wave gives up after that many inner nodes (0 = never) and reports the lanes that were still looking
+// in `unresolved`; their rays are then finished piecewise by other lanes (mesh_traverse_seg).
 template <int MODE>
-__device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, double bound, MeshHit& mh, Visits& vc) {
+__device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, double bound, MeshHit& mh, Visits& vc,
+                                uint32_t budget, unsigned long long& unresolved) {
     mh.n = 0; mh.t0 = bound; mh.t1 = bound; mh.r0 = 0;
+    unresolved = 0;
+    uint32_t steps = 0;
     const DNode* nodes = uni_ptr(Mg.nodes);
     const DTri* tris = uni_ptr(Mg.tris);
     float limit = __double2float_ru(bound);
     bool found = false;
+    const PRay pr = pray_new(ray);
 
     float tn_root;
     const bool root_hit = active && node_box(Mg.root_min, Mg.root_max, ray, tn_root) && !(tn_root > limit);
@@ -128,6 +167,7 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
             cur = RT_POP;
         } else {
             // ---- an inner node: four boxes against every lane that entered the node
+            if (budget && ++steps > budget) { unresolved = alive & ~__ballot(found); break; }
             const UNode n = load_unode(nodes, cur);
             const bool in = lane_in(curmask & alive);
             if (in) vc.nodes++;
@@ -173,6 +213,7 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
 __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active, Closest& c, Visits& vc) {
     c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
     bool any = false;
+    unsigned long long unres = 0;
     const uint32_t n = S.n_objects;
     const RT_GLOBAL DObject* objs = gptr(S.objects);
     for (uint32_t oi = 0; oi < n; oi++) {
@@ -184,7 +225,7 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
                 if (active && mesh_traverse<TRAV_TWO>(S.meshes[payload], ray, INFINITY, mh, vc) && (!any || mh.t0 < c.t)) {
                     c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.n >= 2 ? mh.t1 : mh.t0; c.u = mh.u; c.v = mh.v; any = true;
                 }
-            } else if (packet_traverse<TRAV_CLOSEST>(S.meshes[payload], ray, active, any ? c.t : INFINITY, mh, vc)) {
+            } else if (packet_traverse<TRAV_CLOSEST>(S.meshes[payload], ray, active, any ? c.t : INFINITY, mh, vc, 0, unres)) {
                 c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.t0; c.u = mh.u; c.v = mh.v; any = true;
             }
             continue;
@@ -199,16 +240,23 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
     return any;
 }
 
-// Shadow cast for a whole wave (sun.rs:89, point.rs:91-92)
-__device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bool limited, double dist, Visits& vc) {
+// Shadow cast for a whole wave (sun.rs:89, point.rs:91-92).  With a budget, a wave whose mesh walk runs long gives
+// up: `unresolved` then holds the lanes whose cast is still open (none of the objects after that mesh were tried
+// for them), to be cast again piecewise.
+__device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bool limited, double dist, Visits& vc,
+                                uint32_t budget, unsigned long long& unresolved) {
     const uint32_t n = S.n_objects;
     const RT_GLOBAL DObject* objs = gptr(S.objects);
     bool blocked = false;
+    unresolved = 0;
     for (uint32_t oi = 0; oi < n; oi++) {
         const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload);
         if (kind == 3) {
             MeshHit mh;
-            if (packet_traverse<TRAV_ANY>(S.meshes[payload], ray, active && !blocked, limited ? dist : INFINITY, mh, vc)) blocked = true;
+            unsigned long long unres = 0;
+            if (packet_traverse<TRAV_ANY>(S.meshes[payload], ray, active && !blocked, limited ? dist : INFINITY, mh, vc, budget, unres)) blocked = true;
+            // every lane that is not blocked yet is cast again: the objects after this mesh were not tried for any of them
+            if (unres) { unresolved = __ballot(active && !blocked); return blocked; }
             continue;
         }
         if (active && !blocked) {

@@ -207,7 +207,7 @@ DEV bool box_intersect(D3 pos, D3 size, const Ray& ray, Hit& h) {
 // fmaxf/fminf exactly as f64::max/min ignore them in the reference.  (ax..az: the bounds the ray meets
 // first on each axis, bx..bz: the ones it meets last.)
 #define RT_CULL_SLACK 9.5367431640625e-07f
-DEV bool slab_test(float ax, float ay, float az, float bx, float by, float bz, const Ray& ray, float& tn_out) {
+DEV bool slab_test2(float ax, float ay, float az, float bx, float by, float bz, const Ray& ray, float& tn_out, float& tf_out) {
     const float t1x = ((ax - ray.ohx) - ray.olx) * ray.mfx, t2x = ((bx - ray.ohx) - ray.olx) * ray.mfx;
     const float t1y = ((ay - ray.ohy) - ray.oly) * ray.mfy, t2y = ((by - ray.ohy) - ray.oly) * ray.mfy;
     const float t1z = ((az - ray.ohz) - ray.olz) * ray.mfz, t2z = ((bz - ray.ohz) - ray.olz) * ray.mfz;
@@ -215,13 +215,22 @@ DEV bool slab_test(float ax, float ay, float az, float bx, float by, float bz, c
     float tf = fminf(fminf(t2x, t2y), t2z);
     tn = tn - fabsf(tn) * RT_CULL_SLACK;
     tf = tf + fabsf(tf) * RT_CULL_SLACK;
-    tn_out = tn;
+    tn_out = tn; tf_out = tf;
     return !(tn > tf || tf < 0.f);
+}
+DEV bool slab_test(float ax, float ay, float az, float bx, float by, float bz, const Ray& ray, float& tn_out) {
+    float tf;
+    return slab_test2(ax, ay, az, bx, by, bz, ray, tn_out, tf);
+}
+template <typename FP>
+DEV bool node_box2(FP bmin, FP bmax, const Ray& ray, float& tn_out, float& tf_out) {
+    return slab_test2(ray.nx ? bmax[0] : bmin[0], ray.ny ? bmax[1] : bmin[1], ray.nz ? bmax[2] : bmin[2],
+                      ray.nx ? bmin[0] : bmax[0], ray.ny ? bmin[1] : bmax[1], ray.nz ? bmin[2] : bmax[2], ray, tn_out, tf_out);
 }
 template <typename FP>
 DEV bool node_box(FP bmin, FP bmax, const Ray& ray, float& tn_out) {
-    return slab_test(ray.nx ? bmax[0] : bmin[0], ray.ny ? bmax[1] : bmin[1], ray.nz ? bmax[2] : bmin[2],
-                     ray.nx ? bmin[0] : bmax[0], ray.ny ? bmin[1] : bmax[1], ray.nz ? bmin[2] : bmax[2], ray, tn_out);
+    float tf;
+    return node_box2(bmin, bmax, ray, tn_out, tf);
 }
 
 // mesh.rs:25-59 with the edges precomputed
@@ -309,10 +318,19 @@ enum { TRAV_CLOSEST = 0, TRAV_TWO = 1, TRAV_ANY = 2 };
         (ta) = tx_; (tb) = ty_; (ra) = rx_; (rb) = ry_;                       \
     } while (0)
 
-template <int MODE>
-__device__ bool mesh_traverse(const DMesh& M, const Ray& ray, double bound, MeshHit& mh, Visits& vc) {
+// A walk can be restricted (SEG): it then enters only boxes whose slab interval [tn, tf] meets [lo, hi], and gives
+// up after `budget` inner nodes (0 = never), setting `aborted`.  Restricting the BOXES does not restrict the hits: a
+// triangle found in a visited leaf counts wherever along the ray it is hit.  So K walks over K intervals that
+// cover the ray together test every triangle the unrestricted walk tests, and the best of their answers (nearest,
+// ties to the lower leaf-order index; or "any") is the unrestricted answer -- a long ray can be cut into pieces
+// that run in parallel lanes.
+struct Seg { float lo, hi; uint32_t budget; };
+
+template <int MODE, bool SEG>
+__device__ bool mesh_traverse_seg(const DMesh& M, const Ray& ray, double bound, MeshHit& mh, Visits& vc, const Seg seg, bool& aborted) {
     mh.n = 0; mh.t0 = bound; mh.t1 = bound; mh.r0 = 0;   // r0 = 0: a hit AT an outside bound never wins the tie
     float tn_root;
+    uint32_t steps = 0;
 #ifdef RT_EXP_NOTRAV
     if (MODE == TRAV_ANY) return false;
 #endif
@@ -333,16 +351,22 @@ __device__ bool mesh_traverse(const DMesh& M, const Ray& ray, double bound, Mesh
         while (!(cur & RT_LEAF_BIT)) {
             const GNodePtr nd = &nodes[cur];
             vc.nodes++;
+            if (SEG && seg.budget && ++steps > seg.budget) { aborted = true; return false; }
             float t0, t1, t2, t3;
             // near/far plane of each child on each axis, by the sign of the direction
-            const bool h0 = slab_test(ray.nx ? nd->maxx[0] : nd->minx[0], ray.ny ? nd->maxy[0] : nd->miny[0], ray.nz ? nd->maxz[0] : nd->minz[0],
-                                      ray.nx ? nd->minx[0] : nd->maxx[0], ray.ny ? nd->miny[0] : nd->maxy[0], ray.nz ? nd->minz[0] : nd->maxz[0], ray, t0);
-            const bool h1 = slab_test(ray.nx ? nd->maxx[1] : nd->minx[1], ray.ny ? nd->maxy[1] : nd->miny[1], ray.nz ? nd->maxz[1] : nd->minz[1],
-                                      ray.nx ? nd->minx[1] : nd->maxx[1], ray.ny ? nd->miny[1] : nd->maxy[1], ray.nz ? nd->minz[1] : nd->maxz[1], ray, t1);
-            const bool h2 = slab_test(ray.nx ? nd->maxx[2] : nd->minx[2], ray.ny ? nd->maxy[2] : nd->miny[2], ray.nz ? nd->maxz[2] : nd->minz[2],
-                                      ray.nx ? nd->minx[2] : nd->maxx[2], ray.ny ? nd->miny[2] : nd->maxy[2], ray.nz ? nd->minz[2] : nd->maxz[2], ray, t2);
-            const bool h3 = slab_test(ray.nx ? nd->maxx[3] : nd->minx[3], ray.ny ? nd->maxy[3] : nd->miny[3], ray.nz ? nd->maxz[3] : nd->minz[3],
-                                      ray.nx ? nd->minx[3] : nd->maxx[3], ray.ny ? nd->miny[3] : nd->maxy[3], ray.nz ? nd->minz[3] : nd->maxz[3], ray, t3);
+            float f0, f1, f2, f3;
+            bool h0 = slab_test2(ray.nx ? nd->maxx[0] : nd->minx[0], ray.ny ? nd->maxy[0] : nd->miny[0], ray.nz ? nd->maxz[0] : nd->minz[0],
+                                 ray.nx ? nd->minx[0] : nd->maxx[0], ray.ny ? nd->miny[0] : nd->maxy[0], ray.nz ? nd->minz[0] : nd->maxz[0], ray, t0, f0);
+            bool h1 = slab_test2(ray.nx ? nd->maxx[1] : nd->minx[1], ray.ny ? nd->maxy[1] : nd->miny[1], ray.nz ? nd->maxz[1] : nd->minz[1],
+                                 ray.nx ? nd->minx[1] : nd->maxx[1], ray.ny ? nd->miny[1] : nd->maxy[1], ray.nz ? nd->minz[1] : nd->maxz[1], ray, t1, f1);
+            bool h2 = slab_test2(ray.nx ? nd->maxx[2] : nd->minx[2], ray.ny ? nd->maxy[2] : nd->miny[2], ray.nz ? nd->maxz[2] : nd->minz[2],
+                                 ray.nx ? nd->minx[2] : nd->maxx[2], ray.ny ? nd->miny[2] : nd->maxy[2], ray.nz ? nd->minz[2] : nd->maxz[2], ray, t2, f2);
+            bool h3 = slab_test2(ray.nx ? nd->maxx[3] : nd->minx[3], ray.ny ? nd->maxy[3] : nd->miny[3], ray.nz ? nd->maxz[3] : nd->minz[3],
+                                 ray.nx ? nd->minx[3] : nd->maxx[3], ray.ny ? nd->miny[3] : nd->maxy[3], ray.nz ? nd->minz[3] : nd->maxz[3], ray, t3, f3);
+            if (SEG) {
+                h0 = h0 && !(t0 > seg.hi) && !(f0 < seg.lo); h1 = h1 && !(t1 > seg.hi) && !(f1 < seg.lo);
+                h2 = h2 && !(t2 > seg.hi) && !(f2 < seg.lo); h3 = h3 && !(t3 > seg.hi) && !(f3 < seg.lo);
+            }
             uint32_t r0 = nd->ref[0], r1 = nd->ref[1], r2 = nd->ref[2], r3 = nd->ref[3];
             // a child that is missed, entered beyond the limit, or absent sorts last with distance +inf
             t0 = (h0 && !(t0 > limit)) ? t0 : INF;
@@ -412,6 +436,27 @@ __device__ bool mesh_traverse(const DMesh& M, const Ray& ray, double bound, Mesh
         }
     }
     return mh.n > 0;
+}
+template <int MODE>
+__device__ bool mesh_traverse(const DMesh& M, const Ray& ray, double bound, MeshHit& mh, Visits& vc) {
+    Seg none; none.lo = 0.f; none.hi = 0.f; none.budget = 0;
+    bool aborted = false;
+    return mesh_traverse_seg<MODE, false>(M, ray, bound, mh, vc, none, aborted);
+}
+
+// The piece of a ray's passage through a mesh's root box that lane `k` of `K` walks (the first piece is open
+// towards -inf and the last towards +inf, so that together they cover every box the plain walk can enter)
+DEV Seg mesh_segment(const DMesh& M, const Ray& ray, double bound, uint32_t k, uint32_t K) {
+    const float INF = __uint_as_float(0x7F800000u);
+    float tn, tf;
+    Seg sg; sg.lo = -INF; sg.hi = INF; sg.budget = 0;
+    if (!node_box2(M.root_min, M.root_max, ray, tn, tf)) return sg;   // the walk returns at its own root test
+    const float a = fmaxf(tn, 0.f), b = fminf(tf, __double2float_ru(bound));
+    if (!(b > a)) return sg;
+    const float step = (b - a) / (float)K;
+    if (k > 0) sg.lo = a + step * (float)k;
+    if (k + 1 < K) sg.hi = a + step * (float)(k + 1);
+    return sg;
 }
 
 // mesh.rs:348-439 from a traversal result (nearest triangle, its barycentrics,
@@ -494,6 +539,70 @@ __device__ bool cast_closest(const DScene& S, const Ray& ray, Closest& c, Visits
         if (hit && (!any || near < c.t)) { c.obj = oi; c.rank = RT_NONE; c.t = near; any = true; }
     }
     return any;
+}
+
+// cast_closest with every plain mesh walk restricted to `sg_of(mesh)`: `k`/`K` pick the piece (K = 1: the whole
+// ray), `budget` bounds each walk.  aborted = some walk gave up; the result is then incomplete.
+__device__ bool cast_closest_seg(const DScene& S, const Ray& ray, Closest& c, Visits& vc, uint32_t k, uint32_t K, uint32_t budget, bool& aborted) {
+    c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
+    bool any = false;
+    aborted = false;
+    const uint32_t n = S.n_objects;
+    const RT_GLOBAL DObject* objs = gptr(S.objects);
+    for (uint32_t oi = 0; oi < n; oi++) {
+        struct { uint32_t kind, payload, need_far; } o;
+        o.kind = objs[oi].kind; o.payload = objs[oi].payload; o.need_far = objs[oi].need_far;
+        double near; bool hit;
+        if (o.kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)o.payload, ray, near);
+        else if (o.kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)o.payload, ray, near);
+        else if (o.kind == 2) hit = box_near(gptr(S.boxes) + 6 * (size_t)o.payload, ray, near);
+        else {
+            MeshHit mh;
+            if (o.need_far) {
+                hit = mesh_traverse<TRAV_TWO>(S.meshes[o.payload], ray, INFINITY, mh, vc);
+                if (hit && (!any || mh.t0 < c.t)) {
+                    c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.n >= 2 ? mh.t1 : mh.t0; c.u = mh.u; c.v = mh.v; any = true;
+                }
+            } else {
+                const double bound = any ? c.t : INFINITY;
+                Seg sg;
+                if (K > 1) sg = mesh_segment(S.meshes[o.payload], ray, bound, k, K);
+                else { sg.lo = -INFINITY; sg.hi = INFINITY; }
+                sg.budget = budget;
+                bool ab = false;
+                hit = mesh_traverse_seg<TRAV_CLOSEST, true>(S.meshes[o.payload], ray, bound, mh, vc, sg, ab);
+                if (ab) { aborted = true; return false; }
+                if (hit) { c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.t0; c.u = mh.u; c.v = mh.v; any = true; }
+            }
+            continue;
+        }
+        if (hit && (!any || near < c.t)) { c.obj = oi; c.rank = RT_NONE; c.t = near; any = true; }
+    }
+    return any;
+}
+
+// cast_any with every mesh walk restricted to piece k of K
+__device__ bool cast_any_seg(const DScene& S, const Ray& ray, bool limited, double dist, Visits& vc, uint32_t k, uint32_t K) {
+    const uint32_t n = S.n_objects;
+    const RT_GLOBAL DObject* objs = gptr(S.objects);
+    for (uint32_t oi = 0; oi < n; oi++) {
+        struct { uint32_t kind, payload; } o;
+        o.kind = objs[oi].kind; o.payload = objs[oi].payload;
+        double near; bool hit;
+        if (o.kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)o.payload, ray, near);
+        else if (o.kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)o.payload, ray, near);
+        else if (o.kind == 2) hit = box_near(gptr(S.boxes) + 6 * (size_t)o.payload, ray, near);
+        else {
+            MeshHit mh;
+            const double bound = limited ? dist : INFINITY;
+            Seg sg = mesh_segment(S.meshes[o.payload], ray, bound, k, K);
+            bool ab = false;
+            if (mesh_traverse_seg<TRAV_ANY, true>(S.meshes[o.payload], ray, bound, mh, vc, sg, ab)) return true;
+            continue;
+        }
+        if (hit && (!limited || near <= dist)) return true;
+    }
+    return false;
 }
 
 // Shadow casts.  sun.rs:89: any object the ray hits at all; point.rs:91-92:

@@ -107,14 +107,17 @@ struct DLevel {
 
 enum { NF_DONE = 1, NF_TRANSPARENT = 2, NF_T_REFLECT = 4, NF_REFLECT = 8, NF_EMISSIVE = 16 };
 
-// Frame counters.  The two allocation cursors take one atomic per workgroup; the statistics are spread over
+// Frame counters.  Every level has its own pair of allocation cursors (one atomic per workgroup each), so that the
+// kernels of different levels can be in flight together; the statistics are spread over
 // RT_SHARDS cache lines (a workgroup adds to shard blockIdx % RT_SHARDS) because thousands of adds to ONE word
 // serialise at about 12 ns each and would cost milliseconds per frame.  The host sums the shards.
 #define RT_SHARDS 64
-struct DShard { unsigned long long rays_reflect, rays_transmit, rays_shadow, nodes_visited, tris_tested, wave_nodes, wave_tris, pad[9]; };   // 128 B
-struct DCounters {
-    unsigned long long next_count;   // rays appended to the next level
-    unsigned long long hit_count;    // lit hits of the current level (length of the k_shadow work list)
-    unsigned long long pad[14];
-    DShard shard[RT_SHARDS];
+struct DShard { unsigned long long rays_reflect, rays_transmit, rays_shadow, nodes_visited, tris_tested, wave_nodes, wave_tris, max_lane_steps, max_wave_steps, pad[7]; };   // 128 B
+struct DLevelCounts {
+    unsigned long long next_count;   // rays this level appended to the next one
+    unsigned long long hit_count;    // lit hits of this level (length of its k_shadow work list)
+    unsigned long long long_trace;   // rays whose closest-hit walk gave up (entries of the level's long-ray list)
+    unsigned long long long_shadow;  // shadow rays whose wave gave up
+    unsigned long long pad[12];
 };
+struct DCounters { DShard shard[RT_SHARDS]; };

@@ -112,90 +112,205 @@ DEV void block_count3(uint32_t v0, uint32_t v1, uint32_t v2, unsigned long long*
 }
 DEV DShard* my_shard(DCounters* C) { return &C->shard[(blockIdx.x + blockIdx.y * 7u) % RT_SHARDS]; }
 
-// Closest hit of every ray of the level.  Rays whose hit will be lit are appended (in wave order) to the work list
-// of k_shadow together with what a shadow ray needs from the hit: the hit point and the offset origin
-// vnear + normal * EPSILON (sun.rs:88, point.rs:90), stored plane by plane: hs[k * stride + slot], k = 0..5.
-template <bool COUNT, bool PACKET>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, uint32_t n, uint32_t* hitlist, double* hs, uint32_t stride, DCounters* C) {
-    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const DScene& S = *Sp;
+// Long rays.  A ray that skims a large mesh visits thousands of boxes one after the other, and a launch is not done
+// before its slowest ray is: with little other work on the chip (a deep level, a small shard) such rays set the
+// frame time.  A walk therefore gives up after a budget of inner nodes and puts its ray on the level's long-ray list;
+// a second kernel casts each listed ray again as RT_SEGS pieces in RT_SEGS neighbouring lanes (mesh_traverse_seg)
+// and merges their answers.  Lists are bounded: a ray that finds no free entry is simply walked to the end.
+#define RT_SEGS 16             /* pieces per long ray = lanes per long ray */
+#define RT_LONG_CAP 262144     /* entries per long-ray list */
+#define RT_LONG_BLOCKS 512     /* grid of the long-ray kernels (they loop over the list) */
+struct LongParams { uint32_t budget_lane, budget_wave; };
+
+// what k_trace does with the closest hit of ray i: the hit record, and the entry of the shadow work list
+// (hit point and the offset origin vnear + normal * EPSILON of sun.rs:88, point.rs:90) when the hit will be lit
+DEV void trace_finish(const DScene& S, DLevel& L, uint32_t i, bool active, const Ray& ray, bool hit, const Closest& c,
+                      uint32_t* hitlist, double* hs, uint32_t stride, DLevelCounts* LC) {
     bool lit = false;
     D3 vnear = d3(0., 0., 0.), so = d3(0., 0., 0.);
-    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
-    const bool active = i < n && L.hit_obj[i] != RT_INACTIVE;
-    const uint32_t ii = i < n ? i : 0;
-    if (PACKET || active) {
-        // PACKET: the wave's rays are coherent (primary rays of an 8x8 pixel block) and walk the BVH together
-        Ray ray = load_ray(L, ii);
-        Closest c;
-        const bool hit = PACKET ? cast_closest_packet(S, ray, active, c, vc) : cast_closest(S, ray, c, vc);
-        if (active) {
-            L.hit_obj[i] = c.obj; L.hit_prim[i] = c.rank;
-            L.hit_t[i] = c.t; L.hit_t2[i] = c.t2; L.hit_u[i] = c.u; L.hit_v[i] = c.v;
-        }
-        if (active && hit && S.n_lights != 0) {
-            const RT_GLOBAL DObject* op = gptr(S.objects) + c.obj;
-            if (!(gptr(S.materials)[op->material].emissivity == 1.)) {      // scene.rs:105-107: fully emissive = no lighting
-                Hit h;
-                closest_hit_fill(S, ray, c.obj, c.rank, c.t, c.t2, c.u, c.v, h);
-                vnear = h.vnear;
-                so = h.vnear + h.normal * RT_EPSILON;
-                lit = true;
-            }
+    if (active) {
+        L.hit_obj[i] = c.obj; L.hit_prim[i] = c.rank;
+        L.hit_t[i] = c.t; L.hit_t2[i] = c.t2; L.hit_u[i] = c.u; L.hit_v[i] = c.v;
+    }
+    if (active && hit && S.n_lights != 0) {
+        const RT_GLOBAL DObject* op = gptr(S.objects) + c.obj;
+        if (!(gptr(S.materials)[op->material].emissivity == 1.)) {      // scene.rs:105-107: fully emissive = no lighting
+            Hit h;
+            closest_hit_fill(S, ray, c.obj, c.rank, c.t, c.t2, c.u, c.v, h);
+            vnear = h.vnear;
+            so = h.vnear + h.normal * RT_EPSILON;
+            lit = true;
         }
     }
-    const uint32_t slot = block_append(lit, &C->hit_count);
+    const uint32_t slot = block_append(lit, &LC->hit_count);
     if (lit) {
         hitlist[slot] = i;
         hs[slot] = vnear.x; hs[(size_t)stride + slot] = vnear.y; hs[2 * (size_t)stride + slot] = vnear.z;
         hs[3 * (size_t)stride + slot] = so.x; hs[4 * (size_t)stride + slot] = so.y; hs[5 * (size_t)stride + slot] = so.z;
     }
+}
+
+// Closest hit of every ray of the level.  Rays whose hit will be lit are appended (in wave order) to the work list
+// of k_shadow, stored plane by plane: hs[k * stride + slot], k = 0..5.
+template <bool COUNT, bool PACKET>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, uint32_t n, uint32_t* hitlist, double* hs, uint32_t stride,
+                                                    DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const DScene& S = *Sp;
+    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
+    bool active = i < n && L.hit_obj[i] != RT_INACTIVE;
+    const uint32_t ii = i < n ? i : 0;
+    Ray ray = load_ray(L, ii);
+    Closest c; c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
+    bool hit = false;
+    if (PACKET) {
+        // the wave's rays are coherent (primary rays of an 8x8 pixel block) and walk the BVH together
+        hit = cast_closest_packet(S, ray, active, c, vc);
+    } else if (active) {
+        bool aborted = false;
+        hit = cast_closest_seg(S, ray, c, vc, 0, 1, lp.budget_lane, aborted);
+        if (aborted) {
+            const unsigned long long e = atomicAdd(&LC->long_trace, 1ull);
+            if (e < RT_LONG_CAP) { longlist[e] = i; active = false; hit = false; }   // k_long_trace finishes this ray
+            else hit = cast_closest(S, ray, c, vc);
+        }
+    }
+    trace_finish(S, L, i, active, ray, hit, c, hitlist, hs, stride, LC);
     if (COUNT) {
         DShard* sh = my_shard(C);
+        if (PACKET) { if (lane_id() == 0) atomicMax(&sh->max_wave_steps, (unsigned long long)(vc.wnodes + vc.wtris)); }
+        else atomicMax(&sh->max_lane_steps, (unsigned long long)(vc.nodes + vc.tris));
         block_count3(vc.nodes, vc.tris, 0, &sh->nodes_visited, &sh->tris_tested, nullptr);
         block_count3(lane_id() == 0 ? vc.wnodes : 0, lane_id() == 0 ? vc.wtris : 0, 0, &sh->wave_nodes, &sh->wave_tris, nullptr);
     }
 }
 
-// One thread per (lit hit, light): the light's shadow cast (sun.rs:87-94, point.rs:68-76,89-99).  Lanes of a wave
-// share the light and walk neighbouring hit points, so their shadow rays are coherent.  A light casts no ray
-// where it has shadows off (sun) or lies beyond max_distance (point: LightShading::default()).
-// occ[light * stride + ray] = 1 when shadowed.
+// The listed long rays of a level, RT_SEGS lanes each: lane k walks piece k of the ray through every mesh, the
+// pieces' answers are merged (nearest; ties to the lower object index, then to the lower leaf-order index --
+// the order cast_ray_once's stable sort gives, scene.rs:57-82), and lane 0 of the group does what k_trace does.
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride, DCounters* C) {
+__global__ __launch_bounds__(RT_BLOCK) void k_long_trace(const DScene* Sp, DLevel L, const uint32_t* longlist, uint32_t* hitlist, double* hs,
+                                                         uint32_t stride, DCounters* C, DLevelCounts* LC) {
+    const DScene& S = *Sp;
+    const unsigned long long listed = LC->long_trace;
+    const uint32_t n_long = listed < RT_LONG_CAP ? (uint32_t)listed : RT_LONG_CAP;
+    const uint32_t per_block = RT_BLOCK / RT_SEGS;
+    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
+    for (uint32_t base = blockIdx.x * per_block; base < n_long; base += gridDim.x * per_block) {   // uniform per block
+        const uint32_t j = base + threadIdx.x / RT_SEGS, k = threadIdx.x % RT_SEGS;
+        const bool have = j < n_long;
+        const uint32_t i = have ? longlist[j] : 0;
+        Ray ray = load_ray(L, i);
+        Closest c; bool ab = false;
+        bool hit = cast_closest_seg(S, ray, c, vc, k, RT_SEGS, 0, ab);
+        // merge over the group's lanes
+        for (int off = 1; off < RT_SEGS; off <<= 1) {
+            const bool oh = __shfl_xor((int)hit, off) != 0;
+            Closest o;
+            o.obj = (uint32_t)__shfl_xor((int)c.obj, off); o.rank = (uint32_t)__shfl_xor((int)c.rank, off);
+            o.t = __shfl_xor(c.t, off); o.t2 = __shfl_xor(c.t2, off); o.u = __shfl_xor(c.u, off); o.v = __shfl_xor(c.v, off);
+            const bool better = oh && (!hit || o.t < c.t || (o.t == c.t && (o.obj < c.obj || (o.obj == c.obj && o.rank < c.rank))));
+            if (better) { c = o; hit = true; }
+        }
+        trace_finish(S, L, i, have && k == 0, ray, hit, c, hitlist, hs, stride, LC);
+    }
+    if (COUNT) { DShard* sh = my_shard(C); block_count3(vc.nodes, vc.tris, 0, &sh->nodes_visited, &sh->tris_tested, nullptr); }
+}
+
+// The shadow ray of lit hit `hh` towards light `Lt` (sun.rs:87-94, point.rs:68-76,89-99).  cast = 0: the light casts
+// no ray here (sun with shadows off; point light beyond max_distance: LightShading::default()).
+DEV Ray shadow_ray(const RT_GLOBAL DLight* Lt, const double* hs, uint32_t stride, uint32_t hh, uint32_t& cast, bool& limited, double& dist) {
+    const D3 vnear = d3(hs[hh], hs[(size_t)stride + hh], hs[2 * (size_t)stride + hh]);
+    const D3 so = d3(hs[3 * (size_t)stride + hh], hs[4 * (size_t)stride + hh], hs[5 * (size_t)stride + hh]);
+    const D3 lv = d3(Lt->v[0], Lt->v[1], Lt->v[2]);
+    limited = false; dist = 0.;
+    D3 dir;
+    if (Lt->kind == 0) {
+        cast = Lt->shadows ? 1u : 0u;
+        dir = -lv;
+    } else {
+        D3 lvec = lv - vnear;
+        dist = magnitude(lvec);
+        cast = dist > Lt->max_distance ? 0u : 1u;
+        dir = lvec / dist;
+        limited = true;
+    }
+    return ray_new(so, dir);
+}
+
+// One thread per (lit hit, light): the light's shadow cast.  Lanes of a wave
+// share the light and walk neighbouring hit points, so their shadow rays are coherent.
+// occ[light * stride + ray] = 1 when shadowed.
+// (held to 64 VGPRs = 8 waves per SIMD: the walk waits on one scalar fetch per step, and waves hide that)
+#ifndef RT_SHADOW_WAVES
+#define RT_SHADOW_WAVES 8, 8
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHADOW_WAVES))) void k_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
+                                                                                                          DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
     const uint32_t h = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t li = blockIdx.y;
     const DScene& S = *Sp;
     Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
     uint32_t cast = 0;
     {
-        const bool have = h < (uint32_t)C->hit_count;
+        const bool have = h < (uint32_t)LC->hit_count;
         const uint32_t hh = have ? h : 0;
-        const RT_GLOBAL DLight* Lt = gptr(S.lights) + li;
-        const D3 vnear = d3(hs[hh], hs[(size_t)stride + hh], hs[2 * (size_t)stride + hh]);
-        const D3 so = d3(hs[3 * (size_t)stride + hh], hs[4 * (size_t)stride + hh], hs[5 * (size_t)stride + hh]);
-        const D3 lv = d3(Lt->v[0], Lt->v[1], Lt->v[2]);
-        bool limited = false; double dist = 0.; D3 dir;
-        if (Lt->kind == 0) {
-            cast = Lt->shadows ? 1u : 0u;
-            dir = -lv;
-        } else {
-            D3 lvec = lv - vnear;
-            dist = magnitude(lvec);
-            cast = dist > Lt->max_distance ? 0u : 1u;
-            dir = lvec / dist;
-            limited = true;
-        }
+        bool limited; double dist;
+        const Ray ray = shadow_ray(gptr(S.lights) + li, hs, stride, hh, cast, limited, dist);
         if (!have) cast = 0;
         // the wave's shadow rays leave neighbouring hit points towards one light: walked as a packet
-        const bool blocked = cast_any_packet(S, ray_new(so, dir), cast != 0, limited, dist, vc);
+        unsigned long long unresolved = 0;
+        const bool blocked = cast_any_packet(S, ray, cast != 0, limited, dist, vc, lp.budget_wave, unresolved);
         if (cast) occ[(size_t)li * stride + hitlist[hh]] = blocked ? 1 : 0;
+        if (unresolved) {
+            // the wave gave up: its open rays go on the long-ray list (k_long_shadow sets their byte when blocked)
+            const uint32_t cnt = (uint32_t)__popcll(unresolved);
+            unsigned long long base = 0;
+            if (lane_id() == 0) base = atomicAdd(&LC->long_shadow, (unsigned long long)cnt);
+            base = ((unsigned long long)uni((uint32_t)(base >> 32)) << 32) | uni((uint32_t)base);
+            if (base + cnt <= RT_LONG_CAP) {
+                if (lane_in(unresolved)) {
+                    const unsigned long long e = base + __popcll(unresolved & ((1ull << lane_id()) - 1ull));
+                    longlist[2 * e] = hh; longlist[2 * e + 1] = li;
+                }
+            } else {
+                // no room: the wave walks its open rays to the end itself
+                unsigned long long none = 0;
+                const bool open = lane_in(unresolved);
+                if (cast_any_packet(S, ray, open, limited, dist, vc, 0, none) && open) occ[(size_t)li * stride + hitlist[hh]] = 1;
+            }
+        }
     }
     DShard* sh = my_shard(C);
     if (COUNT) {
+        if (lane_id() == 0) atomicMax(&sh->max_wave_steps, (unsigned long long)(vc.wnodes + vc.wtris));
         block_count3(cast, vc.nodes, vc.tris, &sh->rays_shadow, &sh->nodes_visited, &sh->tris_tested);
         block_count3(lane_id() == 0 ? vc.wnodes : 0, lane_id() == 0 ? vc.wtris : 0, 0, &sh->wave_nodes, &sh->wave_tris, nullptr);
     } else block_count3(cast, 0, 0, &sh->rays_shadow, nullptr, nullptr);
+}
+
+// The listed long shadow rays, RT_SEGS lanes each: any piece that finds a blocker sets the ray's byte.
+// Entries past the list's capacity were never written (their waves finished their rays themselves); the list is
+// filled with 0xFF before the frame, so an unwritten entry in range shows as light index 0xFFFFFFFF.
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_long_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
+                                                          DCounters* C, const DLevelCounts* LC, const uint32_t* longlist) {
+    const DScene& S = *Sp;
+    const unsigned long long listed = LC->long_shadow;
+    const uint32_t n_long = listed < RT_LONG_CAP ? (uint32_t)listed : RT_LONG_CAP;
+    const uint32_t per_block = RT_BLOCK / RT_SEGS;
+    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
+    for (uint32_t base = blockIdx.x * per_block; base < n_long; base += gridDim.x * per_block) {
+        const uint32_t j = base + threadIdx.x / RT_SEGS, k = threadIdx.x % RT_SEGS;
+        if (j >= n_long) continue;
+        const uint32_t hh = longlist[2 * (size_t)j], li = longlist[2 * (size_t)j + 1];
+        if (li >= S.n_lights) continue;
+        uint32_t cast; bool limited; double dist;
+        const Ray ray = shadow_ray(gptr(S.lights) + li, hs, stride, hh, cast, limited, dist);
+        if (cast && cast_any_seg(S, ray, limited, dist, vc, k, RT_SEGS)) occ[(size_t)li * stride + hitlist[hh]] = 1;
+    }
+    if (COUNT) { DShard* sh = my_shard(C); block_count3(vc.nodes, vc.tris, 0, &sh->nodes_visited, &sh->tris_tested, nullptr); }
 }
 
 // One light's contribution (lighting/sun.rs:72-97, point.rs:66-105) given its shadow cast's result
@@ -223,9 +338,12 @@ DEV void light_shading(const DLight& Lt, const Ray& ray, const Hit& hit, bool sh
     intensity = Lt.intensity / (q * q);
 }
 
+// What a hit spawns (scene.rs:129-196): the transmitted ray (child 0) and the reflected ray (child 1), the blend
+// flags and the reflection weight.  Needs the hit only, not the lighting, so the next level can be traced while this
+// level's shadow rays are still in flight.
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, DLevel N, uint32_t n, uint32_t depth,
-                                                    uint32_t next_cap, DCounters* C, uint32_t* ids_out, const uint8_t* occ, uint32_t stride) {
+__global__ __launch_bounds__(RT_BLOCK) void k_spawn(const DScene* Sp, DLevel L, DLevel N, uint32_t n, uint32_t depth,
+                                                    uint32_t next_cap, DCounters* C, DLevelCounts* LC, uint32_t* ids_out) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     const DScene& S = *Sp;
     bool active = i < n;
@@ -236,7 +354,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, 
         active = false;
     }
     Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
-    bool want0 = false, want1 = false;
+    bool want0 = false, want1 = false, pending = false;
     D3 c0o = d3(0, 0, 0), c0d = d3(0, 0, 1), c1o = d3(0, 0, 0), c1d = d3(0, 0, 1);
 
     if (active) {
@@ -251,22 +369,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, 
             if (ids_out && depth == 0) { ids_out[2 * (size_t)i] = obj; ids_out[2 * (size_t)i + 1] = hit.prim; }
             const DMaterial& mat = S.materials[S.objects[obj].material];
             const uint32_t base_rgb = texture_at(mat, hit.u, hit.v);       // scene.rs:102
-            D3 color = to_d3(base_rgb);
             if (mat.emissivity == 1.) {                                    // scene.rs:105-107
-                L.result[i] = to_color(color);
+                L.result[i] = to_color(to_d3(base_rgb));
                 L.base_flags[i] = (uint32_t)NF_DONE << 24;
             } else {
-                D3 sum = ld3(S.ambient);                                   // scene.rs:110-120
-                for (uint32_t li = 0; li < S.n_lights; li++) {
-                    const DLight& Lt = S.lights[li];
-                    double diff = 0., spec = 0., inten = 0.;
-                    light_shading(Lt, ray, hit, occ[(size_t)li * stride + i] != 0, diff, spec, inten);
-                    D3 lcol = ld3(Lt.col);
-                    D3 dv = lcol * diff;
-                    D3 sv = lcol * (spec * Lt.specular_strength);
-                    sum = sum + (dv + sv) * inten;
-                }
-                color = color * sum;                                       // scene.rs:122
                 uint32_t flags = 0;
                 double w_r = 0.;
                 const double refl = mat.reflectiveness, transp = mat.transparency, ior = mat.ior;
@@ -307,26 +413,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, 
                     c1d = ray.d - hit.normal * (2. * dot(ray.d, hit.normal));
                 }
                 if (mat.emissivity > 0.) flags |= NF_EMISSIVE;             // scene.rs:200-205
-                if (!want0 && !want1) {
-                    // no child calls: the result is final now
-                    if (flags & NF_TRANSPARENT) color = vlerp(color, color, transp);     // :179 with transparency_color == color
-                    if (flags & NF_EMISSIVE) color = vlerp(color, to_d3(base_rgb), mat.emissivity);
-                    L.result[i] = to_color(color);
-                    L.base_flags[i] = (uint32_t)NF_DONE << 24;
-                } else {
-                    L.lit[0][i] = color.x; L.lit[1][i] = color.y; L.lit[2][i] = color.z;
-                    L.w_t[i] = transp; L.w_r[i] = w_r; L.emis[i] = mat.emissivity;
-                    L.base_flags[i] = (base_rgb & 0xFFFFFFu) | (flags << 24);
-                }
+                L.w_t[i] = transp; L.w_r[i] = w_r; L.emis[i] = mat.emissivity;
+                L.base_flags[i] = (base_rgb & 0xFFFFFFu) | (flags << 24);   // k_light finishes it
+                pending = true;
             }
         }
     }
     // append the children to the next level (whole wave takes part)
     uint32_t s0, s1;
-    block_append2(want0, want1, &C->next_count, s0, s1);
+    block_append2(want0, want1, &LC->next_count, s0, s1);
     if (want0 && s0 >= next_cap) want0 = false;
     if (want1 && s1 >= next_cap) want1 = false;
-    if (active && !((L.base_flags[i] >> 24) & NF_DONE)) {
+    if (pending) {
         L.child0[i] = want0 ? s0 : RT_NONE;
         L.child1[i] = want1 ? s1 : RT_NONE;
     }
@@ -335,6 +433,43 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(const DScene* Sp, DLevel L, 
     DShard* sh = my_shard(C);
     block_count3(want0 ? 1u : 0u, want1 ? 1u : 0u, 0, &sh->rays_transmit, &sh->rays_reflect, nullptr);
     if (COUNT) block_count3(vc.nodes, vc.tris, 0, &sh->nodes_visited, &sh->tris_tested, nullptr);
+}
+
+// The lit colour of every hit that k_spawn left pending (scene.rs:102-122), from the shadow casts' results.  A hit
+// without children is final here; the others keep the colour for k_resolve.
+__global__ __launch_bounds__(RT_BLOCK) void k_light(const DScene* Sp, DLevel L, uint32_t n, const uint8_t* occ, uint32_t stride) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t bf = L.base_flags[i];
+    const uint32_t flags = bf >> 24;
+    if (flags & NF_DONE) return;
+    const DScene& S = *Sp;
+    const uint32_t obj = L.hit_obj[i];
+    Ray ray = load_ray(L, i);
+    Hit hit;
+    closest_hit_fill(S, ray, obj, L.hit_prim[i], L.hit_t[i], L.hit_t2[i], L.hit_u[i], L.hit_v[i], hit);
+    const uint32_t base_rgb = bf & 0xFFFFFFu;
+    D3 color = to_d3(base_rgb);
+    D3 sum = ld3(S.ambient);                                   // scene.rs:110-120
+    for (uint32_t li = 0; li < S.n_lights; li++) {
+        const DLight& Lt = S.lights[li];
+        double diff = 0., spec = 0., inten = 0.;
+        light_shading(Lt, ray, hit, occ[(size_t)li * stride + i] != 0, diff, spec, inten);
+        D3 lcol = ld3(Lt.col);
+        D3 dv = lcol * diff;
+        D3 sv = lcol * (spec * Lt.specular_strength);
+        sum = sum + (dv + sv) * inten;
+    }
+    color = color * sum;                                       // scene.rs:122
+    if (L.child0[i] == RT_NONE && L.child1[i] == RT_NONE) {
+        // no child calls: the result is final now
+        if (flags & NF_TRANSPARENT) color = vlerp(color, color, L.w_t[i]);     // :179 with transparency_color == color
+        if (flags & NF_EMISSIVE) color = vlerp(color, to_d3(base_rgb), L.emis[i]);
+        L.result[i] = to_color(color);
+        L.base_flags[i] = (uint32_t)NF_DONE << 24;
+    } else {
+        L.lit[0][i] = color.x; L.lit[1][i] = color.y; L.lit[2][i] = color.z;
+    }
 }
 
 // Folds one level into its parents' view: scene.rs:176-205 on the children's

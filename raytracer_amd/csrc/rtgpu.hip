@@ -24,6 +24,18 @@ thread_local std::string g_create_error = "";
 
 struct LevelAlloc { void* base = nullptr; size_t cap = 0; DLevel lv; };
 
+// Per-level buffers and events of the shadow side of a level, which runs beside the trace of the next level
+struct LevelWork {
+    void* hitlist = nullptr; size_t hitlist_cap = 0;   // rays of the level whose hit is lit
+    void* occ = nullptr; size_t occ_cap = 0;           // shadow results [light][ray]
+    void* hs = nullptr; size_t hs_cap = 0;             // hit point + shadow-ray origin of every lit hit, 6 planes of doubles
+    void* long_trace = nullptr; size_t long_trace_cap = 0;     // long-ray lists (RT_LONG_CAP entries)
+    void* long_shadow = nullptr; size_t long_shadow_cap = 0;
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // see LW_*
+};
+enum { LW_T0, LW_T1, LW_P, LW_S0, LW_S1, LW_L0, LW_L1 };
+#define RT_SIDE_STREAMS 4
+
 }  // namespace
 
 struct rt_ctx {
@@ -42,12 +54,16 @@ struct rt_ctx {
     void* d_out = nullptr; size_t d_out_cap = 0;      // rgb staging for rt_render
     void* d_ids = nullptr; size_t d_ids_cap = 0;      // compact ids
     void* d_ids2 = nullptr; size_t d_ids2_cap = 0;    // row-major ids
-    void* d_hitlist = nullptr; size_t d_hitlist_cap = 0;   // rays of the current level that hit something
-    void* d_occ = nullptr; size_t d_occ_cap = 0;      // shadow results [light][ray] of the current level
-    void* d_hs = nullptr; size_t d_hs_cap = 0;        // hit point + shadow-ray origin of every lit hit, 6 planes of doubles
-    bool count_visits = false;                        // RTGPU_COUNT_VISITS=1: instrumented kernels
+    std::vector<LevelWork> lw;
+    DLevelCounts* d_lcounts = nullptr;                // [n_lcounts], one pair of cursors per level
+    DLevelCounts* h_lcounts = nullptr;                // pinned
+    size_t n_lcounts = 0;
+    hipStream_t side[RT_SIDE_STREAMS] = {nullptr, nullptr, nullptr, nullptr};   // shadow + lighting of level d runs on side[d % N]
+    LongParams long_params = {256u, 256u};            // walk budgets (inner nodes per lane / per wave) before a ray goes on the long-ray list; 0 = off
+    uint32_t long_below = 300000u;                  // ... applied to launches of fewer rays than this
+    int count_visits = 0;                             // RTGPU_COUNT_VISITS: bit 0 k_trace, bit 1 k_shadow, bit 2 k_shade instrumented
     uint32_t n_lights = 0;
-    hipEvent_t ev[8];
+    hipEvent_t ev[4];
     size_t scene_bytes = 0, work_bytes = 0;
     double ms_upload = 0.;
 };
@@ -304,7 +320,36 @@ uint64_t valid_pixels(const ShardMap& m, int32_t vw, int32_t vh) {
     return n;
 }
 
+int ensure_level_work(rt_ctx* c, size_t depth, size_t n) {
+    if (c->lw.size() <= depth) c->lw.resize(depth + 1);
+    LevelWork& W = c->lw[depth];
+    for (auto& e : W.ev) if (!e) HIP_TRY(c, hipEventCreate(&e));
+    int rc;
+    if ((rc = ensure_buf(c, &W.hitlist, &W.hitlist_cap, n * 4)) != RT_OK) return rc;
+    if (c->n_lights && (rc = ensure_buf(c, &W.occ, &W.occ_cap, n * c->n_lights)) != RT_OK) return rc;
+    if ((rc = ensure_buf(c, &W.long_trace, &W.long_trace_cap, (size_t)RT_LONG_CAP * 4)) != RT_OK) return rc;
+    if ((rc = ensure_buf(c, &W.long_shadow, &W.long_shadow_cap, (size_t)RT_LONG_CAP * 8)) != RT_OK) return rc;
+    return ensure_buf(c, &W.hs, &W.hs_cap, n * 48);
+}
+
+int ensure_level_counts(rt_ctx* c, size_t n) {
+    if (c->n_lcounts >= n) return RT_OK;
+    if (c->d_lcounts) (void)hipFree(c->d_lcounts);
+    if (c->h_lcounts) (void)hipHostFree(c->h_lcounts);
+    c->d_lcounts = nullptr; c->h_lcounts = nullptr; c->n_lcounts = 0;
+    if (hipMalloc((void**)&c->d_lcounts, n * sizeof(DLevelCounts)) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipMalloc failed for the level counters");
+    if (hipHostMalloc((void**)&c->h_lcounts, n * sizeof(DLevelCounts), hipHostMallocDefault) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipHostMalloc failed for the level counters");
+    c->n_lcounts = n;
+    return RT_OK;
+}
+
 // The frame: levels 0..max_depth forward, then folded back.
+//
+// Main stream:  k_primary, then per level d  k_trace(d) -> k_spawn(d) -> read back the size of level d+1.
+// Side streams: per level d  k_shadow(d) -> k_light(d), both after k_spawn(d).
+// The shadow casts of a level need only that level's hits, and the next level needs only the spawned rays, so the
+// two chains run side by side: the long tail of a shadow launch (a few rays that skim the whole mesh) overlaps with
+// the trace of the deeper levels instead of idling the chip.  k_resolve waits for every k_light.
 int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st) {
     if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -317,15 +362,17 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
     stats.rays_primary = valid_pixels(map, c->vw, c->vh);
     stats.rays_per_level[0] = stats.rays_primary;
     hipStream_t s = c->stream;
+    int rc;
+    const size_t n_lc = (size_t)c->max_depth + 2;
+    if ((rc = ensure_level_counts(c, n_lc)) != RT_OK) return rc;
     std::memset(c->hcounters, 0, sizeof(DCounters));
     HIP_TRY(c, hipMemsetAsync(c->dcounters, 0, sizeof(DCounters), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_lcounts, 0, n_lc * sizeof(DLevelCounts), s));
 
     std::vector<uint32_t> counts;
     counts.push_back(n0);
-    float ms_trace = 0.f, ms_shadow = 0.f, ms_shade = 0.f, ms_resolve = 0.f;
     uint32_t n_tr = 0, n_sh = 0, n_sd = 0;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    int rc;
     if (n0 > 0) {
         if ((rc = ensure_level(c, 0, n0)) != RT_OK) return rc;
         hipLaunchKernelGGL(k_primary, dim3((n0 + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, c->dscene, c->levels[0].lv, n0, map);
@@ -337,72 +384,108 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
         const bool can_spawn = depth < c->max_depth;
         const size_t next_cap = can_spawn ? std::min<size_t>((size_t)2 * n, 0x7FFFFFFEull) : 1;
         if ((rc = ensure_level(c, depth + 1, next_cap)) != RT_OK) return rc;
-        if ((rc = ensure_buf(c, &c->d_hitlist, &c->d_hitlist_cap, (size_t)n * 4)) != RT_OK) return rc;
-        if (c->n_lights && (rc = ensure_buf(c, &c->d_occ, &c->d_occ_cap, (size_t)n * c->n_lights)) != RT_OK) return rc;
-        if ((rc = ensure_buf(c, &c->d_hs, &c->d_hs_cap, (size_t)n * 48)) != RT_OK) return rc;
-        double* hs = static_cast<double*>(c->d_hs);
-        uint32_t* hitlist = static_cast<uint32_t*>(c->d_hitlist);
-        uint8_t* occ = static_cast<uint8_t*>(c->d_occ);
+        if ((rc = ensure_level_work(c, depth, n)) != RT_OK) return rc;
+        LevelWork& W = c->lw[depth];
+        double* hs = static_cast<double*>(W.hs);
+        uint32_t* hitlist = static_cast<uint32_t*>(W.hitlist);
+        uint8_t* occ = static_cast<uint8_t*>(W.occ);
+        DLevelCounts* lc = c->d_lcounts + depth;
+        uint32_t* long_trace = static_cast<uint32_t*>(W.long_trace);
+        uint32_t* long_shadow = static_cast<uint32_t*>(W.long_shadow);
+        // budgets only where the launch is small enough for its slowest wave to set its duration: in a large
+        // launch the other waves hide a long walk, and cutting it up would only add work
+        LongParams lp = c->long_params;
+        if (n >= c->long_below) { lp.budget_lane = 0; lp.budget_wave = 0; }
+        hipStream_t side = c->side[depth % RT_SIDE_STREAMS];
+        if (c->n_lights && lp.budget_wave) HIP_TRY(c, hipMemsetAsync(long_shadow, 0xFF, (size_t)RT_LONG_CAP * 8, s));
         const dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
-        HIP_TRY(c, hipEventRecord(c->ev[1], s));
+        HIP_TRY(c, hipEventRecord(W.ev[LW_T0], s));
         // depth 0: primary rays, 8x8 pixel blocks per wave -> coherent packets; deeper rays are walked lane by lane
         if (depth == 0) {
-            if (c->count_visits) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters);
-            else hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters);
+            if (c->count_visits & 1) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters, lc, long_trace, lp);
+            else hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters, lc, long_trace, lp);
         } else {
-            if (c->count_visits) hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters);
-            else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters);
+            if (c->count_visits & 1) hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters, lc, long_trace, lp);
+            else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters, lc, long_trace, lp);
         }
-        HIP_TRY(c, hipEventRecord(c->ev[2], s));
+        if (depth > 0 && lp.budget_lane) {
+            if (c->count_visits & 1) hipLaunchKernelGGL(k_long_trace<true>, dim3(RT_LONG_BLOCKS), block, 0, s, c->dscene, c->levels[depth].lv, long_trace, hitlist, hs, n, c->dcounters, lc);
+            else hipLaunchKernelGGL(k_long_trace<false>, dim3(RT_LONG_BLOCKS), block, 0, s, c->dscene, c->levels[depth].lv, long_trace, hitlist, hs, n, c->dcounters, lc);
+        }
+        HIP_TRY(c, hipEventRecord(W.ev[LW_T1], s));
+        if (c->count_visits & 4) hipLaunchKernelGGL(k_spawn<true>, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, depth,
+                                                    (uint32_t)next_cap, c->dcounters, lc, depth == 0 ? d_ids : nullptr);
+        else hipLaunchKernelGGL(k_spawn<false>, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, depth,
+                                (uint32_t)next_cap, c->dcounters, lc, depth == 0 ? d_ids : nullptr);
+        HIP_TRY(c, hipEventRecord(W.ev[LW_P], s));
+        // the shadow casts start after k_spawn, not beside it: the spawn is short but on the frame's critical
+        // path, and next to a chip full of shadow waves it would crawl
+        HIP_TRY(c, hipStreamWaitEvent(side, W.ev[LW_P], 0));
+        HIP_TRY(c, hipEventRecord(W.ev[LW_S0], side));
         if (c->n_lights) {
             // sized for the worst case (every ray hit); threads past the hit count leave at once
             const dim3 sgrid((n + RT_BLOCK - 1) / RT_BLOCK, c->n_lights);
-            if (c->count_visits) hipLaunchKernelGGL(k_shadow<true>, sgrid, block, 0, s, c->dscene, hitlist, hs, occ, n, c->dcounters);
-            else hipLaunchKernelGGL(k_shadow<false>, sgrid, block, 0, s, c->dscene, hitlist, hs, occ, n, c->dcounters);
+            if (c->count_visits & 2) hipLaunchKernelGGL(k_shadow<true>, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc, long_shadow, lp);
+            else hipLaunchKernelGGL(k_shadow<false>, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc, long_shadow, lp);
+            if (lp.budget_wave) {
+                if (c->count_visits & 2) hipLaunchKernelGGL(k_long_shadow<true>, dim3(RT_LONG_BLOCKS), block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc, long_shadow);
+                else hipLaunchKernelGGL(k_long_shadow<false>, dim3(RT_LONG_BLOCKS), block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc, long_shadow);
+            }
             n_sd++;
         }
-        HIP_TRY(c, hipEventRecord(c->ev[6], s));
-        if (c->count_visits) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, depth,
-                                                (uint32_t)next_cap, c->dcounters, depth == 0 ? d_ids : nullptr, occ, n);
-        else hipLaunchKernelGGL(k_shade<false>, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, depth,
-                                (uint32_t)next_cap, c->dcounters, depth == 0 ? d_ids : nullptr, occ, n);
+        HIP_TRY(c, hipEventRecord(W.ev[LW_S1], side));
+        HIP_TRY(c, hipEventRecord(W.ev[LW_L0], side));
+        hipLaunchKernelGGL(k_light, grid, block, 0, side, c->dscene, c->levels[depth].lv, n, occ, n);
+        HIP_TRY(c, hipEventRecord(W.ev[LW_L1], side));
         n_tr++; n_sh++;
-        HIP_TRY(c, hipEventRecord(c->ev[3], s));
-        HIP_TRY(c, hipMemcpyAsync(c->hcounters, c->dcounters, sizeof(DCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(c->h_lcounts + depth, lc, sizeof(DLevelCounts), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         HIP_TRY(c, hipGetLastError());
-        float a = 0.f, b = 0.f, b2 = 0.f;
-        (void)hipEventElapsedTime(&a, c->ev[1], c->ev[2]);
-        (void)hipEventElapsedTime(&b2, c->ev[2], c->ev[6]);
-        (void)hipEventElapsedTime(&b, c->ev[6], c->ev[3]);
-        ms_trace += a; ms_shadow += b2; ms_shade += b;
-        const unsigned long long spawned = c->hcounters->next_count;
-        if (spawned > next_cap) return fail(c, RT_ERR_DEVICE, "wavefront level overflow");
+        const unsigned long long spawned = c->h_lcounts[depth].next_count;
+        if (spawned > next_cap) {
+            for (auto side_s : c->side) (void)hipStreamSynchronize(side_s);
+            return fail(c, RT_ERR_DEVICE, "wavefront level overflow");
+        }
         if (spawned > 0 && can_spawn) {
             counts.push_back((uint32_t)spawned);
             if (depth + 1 < 8) stats.rays_per_level[depth + 1] = spawned;
         }
-        // children of this level were appended at [0, spawned) of the next level: restart its counter
-        HIP_TRY(c, hipMemsetAsync(&c->dcounters->next_count, 0, 2 * sizeof(unsigned long long), s));   // next_count, hit_count
     }
-    HIP_TRY(c, hipEventRecord(c->ev[4], s));
+    const size_t used = std::min<size_t>(counts.size(), c->lw.size());
+    for (size_t d = 0; d < used; d++) if (counts[d] > 0) HIP_TRY(c, hipStreamWaitEvent(s, c->lw[d].ev[LW_L1], 0));
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
     for (int depth = (int)counts.size() - 1; depth >= 0; depth--) {
         const uint32_t n = counts[depth];
         if (n == 0) continue;
         hipLaunchKernelGGL(k_resolve, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, c->dscene, c->levels[depth].lv,
                            c->levels[depth + 1].lv, n, depth == 0 ? 1 : 0, d_rgb, map);
     }
-    HIP_TRY(c, hipEventRecord(c->ev[5], s));
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    HIP_TRY(c, hipMemcpyAsync(c->hcounters, c->dcounters, sizeof(DCounters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_lcounts, c->d_lcounts, n_lc * sizeof(DLevelCounts), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
-    (void)hipEventElapsedTime(&ms_resolve, c->ev[4], c->ev[5]);
-    float ms_all = 0.f;
-    (void)hipEventElapsedTime(&ms_all, c->ev[0], c->ev[5]);
+    for (size_t d = 0; d < counts.size() && d < n_lc; d++) { stats.long_trace += c->h_lcounts[d].long_trace; stats.long_shadow += c->h_lcounts[d].long_shadow; }
+    // per-phase times are sums of the launches' own durations; the phases overlap, so they add up to more than ms_render
+    float ms_trace = 0.f, ms_shadow = 0.f, ms_shade = 0.f, ms_resolve = 0.f, ms_all = 0.f;
+    for (size_t d = 0; d < used; d++) {
+        if (counts[d] == 0) continue;
+        const LevelWork& W = c->lw[d];
+        float a = 0.f, b = 0.f, p = 0.f, l = 0.f;
+        (void)hipEventElapsedTime(&a, W.ev[LW_T0], W.ev[LW_T1]);
+        (void)hipEventElapsedTime(&b, W.ev[LW_S0], W.ev[LW_S1]);
+        (void)hipEventElapsedTime(&p, W.ev[LW_T1], W.ev[LW_P]);
+        (void)hipEventElapsedTime(&l, W.ev[LW_L0], W.ev[LW_L1]);
+        ms_trace += a; ms_shadow += b; ms_shade += p + l;
+    }
+    (void)hipEventElapsedTime(&ms_resolve, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&ms_all, c->ev[0], c->ev[2]);
     for (int k = 0; k < RT_SHARDS; k++) {
         const DShard& sh = c->hcounters->shard[k];
         stats.rays_reflect += sh.rays_reflect; stats.rays_transmit += sh.rays_transmit; stats.rays_shadow += sh.rays_shadow;
         stats.nodes_visited += sh.nodes_visited; stats.tris_tested += sh.tris_tested;
         stats.wave_nodes += sh.wave_nodes; stats.wave_tris += sh.wave_tris;
+        stats.max_lane_steps = std::max<uint64_t>(stats.max_lane_steps, sh.max_lane_steps); stats.max_wave_steps = std::max<uint64_t>(stats.max_wave_steps, sh.max_wave_steps);
     }
     stats.ms_render = ms_all; stats.ms_trace = ms_trace; stats.ms_shadow = ms_shadow; stats.ms_shade = ms_shade; stats.ms_resolve = ms_resolve;
     stats.launches_trace = n_tr; stats.launches_shadow = n_sd; stats.launches_shade = n_sh;
@@ -433,10 +516,20 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     rt_ctx* c = new (std::nothrow) rt_ctx();
     if (!c) { g_create_error = "out of host memory"; return RT_ERR_NOMEM; }
     c->device = device_id;
-    { const char* e = std::getenv("RTGPU_COUNT_VISITS"); c->count_visits = e && e[0] == '1'; }
+    {
+        // "1": every kernel instrumented; "trace" / "shadow" / "shade": only that one (to attribute the counts)
+        const char* e = std::getenv("RTGPU_COUNT_VISITS");
+        const std::string v = e ? e : "";
+        c->count_visits = v == "1" ? 7 : v == "trace" ? 1 : v == "shadow" ? 2 : v == "shade" ? 4 : 0;
+        if (const char* b = std::getenv("RTGPU_BUDGET_LANE")) c->long_params.budget_lane = (uint32_t)std::strtoul(b, nullptr, 10);
+        if (const char* b = std::getenv("RTGPU_BUDGET_WAVE")) c->long_params.budget_wave = (uint32_t)std::strtoul(b, nullptr, 10);
+        if (const char* b = std::getenv("RTGPU_BUDGET_BELOW")) c->long_below = (uint32_t)std::strtoul(b, nullptr, 10);
+    }
     auto bail = [&](const char* what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); delete c; return RT_ERR_DEVICE; };
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    // (all streams at the default priority: mixed priorities hung the frame on this ROCm)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (auto& ss : c->side) if ((e = hipStreamCreateWithFlags(&ss, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipMalloc((void**)&c->dscene, sizeof(DScene))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->dcounters, sizeof(DCounters))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipHostMalloc((void**)&c->hcounters, sizeof(DCounters), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
@@ -449,14 +542,23 @@ void rt_ctx_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto ss : c->side) if (ss) (void)hipStreamSynchronize(ss);
     free_scene(c);
     for (auto& la : c->levels) if (la.base) (void)hipFree(la.base);
+    for (auto& W : c->lw) {
+        if (W.hitlist) (void)hipFree(W.hitlist);
+        if (W.occ) (void)hipFree(W.occ);
+        if (W.hs) (void)hipFree(W.hs);
+        if (W.long_trace) (void)hipFree(W.long_trace);
+        if (W.long_shadow) (void)hipFree(W.long_shadow);
+        for (auto ev : W.ev) if (ev) (void)hipEventDestroy(ev);
+    }
+    if (c->d_lcounts) (void)hipFree(c->d_lcounts);
+    if (c->h_lcounts) (void)hipHostFree(c->h_lcounts);
+    for (auto ss : c->side) if (ss) (void)hipStreamDestroy(ss);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ids) (void)hipFree(c->d_ids);
     if (c->d_ids2) (void)hipFree(c->d_ids2);
-    if (c->d_hitlist) (void)hipFree(c->d_hitlist);
-    if (c->d_occ) (void)hipFree(c->d_occ);
-    if (c->d_hs) (void)hipFree(c->d_hs);
     if (c->dscene) (void)hipFree(c->dscene);
     if (c->dcounters) (void)hipFree(c->dcounters);
     if (c->hcounters) (void)hipHostFree(c->hcounters);

@@ -16,6 +16,12 @@ class Context:
         self.device_id = device_id
         self.vw = self.vh = 0
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def close(self):
         if self._c:
             N.gpu().rt_ctx_destroy(self._c)

@@ -270,3 +270,23 @@ def test_full_size_config4_sampled_and_properties(gpu_ctx):
     obj = ids[..., 0]
     assert set(np.unique(obj)) <= {0, 1, N.RT_ID_NONE}
     assert (ids[..., 1][obj == 0] < 1002528).all() and (ids[..., 1][obj == 1] == N.RT_ID_NONE).all()
+
+
+@pytest.mark.parametrize("builder,args", [
+    (scenes.synthetic_terrain_scene, (256, 144, 48)),
+    (scenes.terrain_scene, (256, 144, 24, 24)),
+    (scenes.small_mixed_scene, (128, 96)),
+])
+def test_long_ray_lists_keep_parity(builder, args, monkeypatch):
+    """walk budgets of a few nodes put most rays on the long-ray lists (16 pieces per ray, merged): same frame"""
+    monkeypatch.setenv("RTGPU_BUDGET_LANE", "3")
+    monkeypatch.setenv("RTGPU_BUDGET_WAVE", "4")
+    monkeypatch.setenv("RTGPU_BUDGET_BELOW", "4000000000")
+    s = builder(*args)
+    with ra.Context(0) as ctx:
+        ctx.upload(s)
+        rgb, ids, st = ctx.render(ids=True)
+    o_rgb, o_ids, o_st, oc = oracle.render(s, 0)
+    assert st.long_trace > 0 and st.long_shadow > 0
+    assert_parity(rgb, ids, o_rgb, o_ids)
+    assert ray_counts(st) == ray_counts(o_st)

@@ -14,5 +14,5 @@ ctx = ra.Context(0)
 ctx.upload(s)
 for _ in range(frames):
     rgb, _, st = ctx.render()
-print(f"frames {frames} ms {st.ms_render:.3f} trace {st.ms_trace:.3f} shadow {st.ms_shadow:.3f} shade {st.ms_shade:.3f} rays {st.rays} nodes {st.nodes_visited} tris {st.tris_tested}")
+print(f"frames {frames} ms {st.ms_render:.3f} trace {st.ms_trace:.3f} shadow {st.ms_shadow:.3f} shade {st.ms_shade:.3f} rays {st.rays} nodes {st.nodes_visited} tris {st.tris_tested} wnodes {st.wave_nodes} wtris {st.wave_tris} long {st.long_trace} {st.long_shadow} max steps lane {st.max_lane_steps} wave {st.max_wave_steps}")
 ctx.close()
