@@ -49,43 +49,50 @@ DEV TriData load_utri(const DTri* tris, uint32_t rank) {
 }
 
 // Per-lane constants of the packet walk's box test.  The slab distance (b - o) * m is evaluated as
-// fma(b, m, c) with c = -(o * m) rounded to f32: one instruction per plane, one rounding of the result.  Against
-// the exact distance the value is off by at most 2^-24 |o m| (rounding of c) plus 2^-23 relative (rounding of m
-// and of the result).  The first is covered by moving c outward per plane (entry planes down, exit planes up),
-// the second by the relative slack after the reductions.  1/direction is clamped to +-1e30 so that an
-// axis-parallel ray gives no inf - inf.
+// fma(b, m, c) with c = -(o * m) rounded to f32: one instruction per plane (two planes with the packed form), one
+// rounding of the result.  Against the exact distance the value is off by at most
+//     2^-24 |o m|  (rounding of c)  +  2^-24 |b m|  (rounding of m)  +  2^-24 |t|  (rounding of the result),
+// and |t| <= (|b| + |o|) |m|, so E = 2^-22 (|o| + B) |m| with B = the largest |coordinate| of the mesh bounds all
+// three.  c is moved outward by E per plane (entry planes down, exit planes up), after which the comparisons need no
+// further slack.  1/direction is clamped to +-1e30 so that an axis-parallel ray gives no inf - inf.
+typedef float __attribute__((ext_vector_type(2))) rt_f2;
 struct PRay { float mx, my, mz, cminx, cminy, cminz, cmaxx, cmaxy, cmaxz; };
-DEV void pray_axis(double o, double m, float& mf, float& cmin, float& cmax) {
+DEV void pray_axis(double o, double m, float B, float& mf, float& cmin, float& cmax) {
     mf = fminf(fmaxf((float)m, -1e30f), 1e30f);
     const double om = o * (double)mf;
-    const float slack = (float)(fabs(om) * 1.2e-7);   // 2^-23 |o m|
+    const float slack = (fabsf((float)o) + B) * fabsf(mf) * 2.4e-7f;   // 2^-22, rounded up
     const float lo = __double2float_rd(-om) - slack, hi = __double2float_ru(-om) + slack;
     const bool pos = !(mf < 0.f);
     cmin = pos ? lo : hi;   // the min plane is the entry plane when the ray runs in +axis direction
     cmax = pos ? hi : lo;
 }
-DEV PRay pray_new(const Ray& r) {
+DEV PRay pray_new(const Ray& r, float B) {
     PRay p;
-    pray_axis(r.o.x, r.m.x, p.mx, p.cminx, p.cmaxx);
-    pray_axis(r.o.y, r.m.y, p.my, p.cminy, p.cmaxy);
-    pray_axis(r.o.z, r.m.z, p.mz, p.cminz, p.cmaxz);
+    pray_axis(r.o.x, r.m.x, B, p.mx, p.cminx, p.cmaxx);
+    pray_axis(r.o.y, r.m.y, B, p.my, p.cminy, p.cmaxy);
+    pray_axis(r.o.z, r.m.z, B, p.mz, p.cminz, p.cmaxz);
     return p;
 }
-DEV bool pslab(float minx, float miny, float minz, float maxx, float maxy, float maxz, const PRay& p, float& tn_out) {
-    const float lx = fmaf(minx, p.mx, p.cminx), hx = fmaf(maxx, p.mx, p.cmaxx);
-    const float ly = fmaf(miny, p.my, p.cminy), hy = fmaf(maxy, p.my, p.cmaxy);
-    const float lz = fmaf(minz, p.mz, p.cminz), hz = fmaf(maxz, p.mz, p.cmaxz);
-    float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fminf(lz, hz));
-    float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fmaxf(lz, hz));
-    tn = fmaf(-fabsf(tn), 4.76837158203125e-07f, tn);   // 2^-21
-    tf = fmaf(fabsf(tf), 4.76837158203125e-07f, tf);
-    tn_out = tn;
-    return !(tn > tf || tf < 0.f);
+// children k and k+1 of a uniform node against this lane's ray: entry and exit distance of each
+#define RT_CHILD_PAIR(n, k, tn_a, tf_a, tn_b, tf_b)                                                                        \
+    do {                                                                                                                  \
+        const rt_f2 lx_ = __builtin_elementwise_fma(rt_f2{asf((n).minx[k]), asf((n).minx[k + 1])}, rt_f2{pr.mx, pr.mx}, rt_f2{pr.cminx, pr.cminx}); \
+        const rt_f2 hx_ = __builtin_elementwise_fma(rt_f2{asf((n).maxx[k]), asf((n).maxx[k + 1])}, rt_f2{pr.mx, pr.mx}, rt_f2{pr.cmaxx, pr.cmaxx}); \
+        const rt_f2 ly_ = __builtin_elementwise_fma(rt_f2{asf((n).miny[k]), asf((n).miny[k + 1])}, rt_f2{pr.my, pr.my}, rt_f2{pr.cminy, pr.cminy}); \
+        const rt_f2 hy_ = __builtin_elementwise_fma(rt_f2{asf((n).maxy[k]), asf((n).maxy[k + 1])}, rt_f2{pr.my, pr.my}, rt_f2{pr.cmaxy, pr.cmaxy}); \
+        const rt_f2 lz_ = __builtin_elementwise_fma(rt_f2{asf((n).minz[k]), asf((n).minz[k + 1])}, rt_f2{pr.mz, pr.mz}, rt_f2{pr.cminz, pr.cminz}); \
+        const rt_f2 hz_ = __builtin_elementwise_fma(rt_f2{asf((n).maxz[k]), asf((n).maxz[k + 1])}, rt_f2{pr.mz, pr.mz}, rt_f2{pr.cmaxz, pr.cmaxz}); \
+        (tn_a) = fmaxf(fmaxf(fminf(lx_.x, hx_.x), fminf(ly_.x, hy_.x)), fminf(lz_.x, hz_.x));                              \
+        (tf_a) = fminf(fminf(fmaxf(lx_.x, hx_.x), fmaxf(ly_.x, hy_.x)), fmaxf(lz_.x, hz_.x));                              \
+        (tn_b) = fmaxf(fmaxf(fminf(lx_.y, hx_.y), fminf(ly_.y, hy_.y)), fminf(lz_.y, hz_.y));                              \
+        (tf_b) = fminf(fminf(fmaxf(lx_.y, hx_.y), fmaxf(ly_.y, hy_.y)), fmaxf(lz_.y, hz_.y));                              \
+    } while (0)
+// lanes (of the whole wave) whose ray meets the box before `limit`: entry <= exit, exit >= 0, entry <= limit.
+// Every value is finite (finite boxes, clamped 1/direction), so the ordered compare needs no NaN case.
+#define RT_FCMP_OLE 5
+DEV unsigned long long box_lanes(float tn, float tf, float limit) {
+    return __builtin_amdgcn_fcmpf(fmaxf(tn, 0.f), fminf(tf, limit), RT_FCMP_OLE);
 }
-
-// slab test of this lane's ray against child k of a uniform node
-#define RT_CHILD_TEST(n, k, tn)                                                                                           \
-    pslab(asf((n).minx[k]), asf((n).miny[k]), asf((n).minz[k]), asf((n).maxx[k]), asf((n).maxy[k]), asf((n).maxz[k]), pr, (tn))
 
 // uniform compare-exchange on (key, ref, mask)
 #define RT_UCSWAP(ka, ra, ma, kb, rb, mb)                                     \
@@ -128,7 +135,7 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
     const DTri* tris = uni_ptr(Mg.tris);
     float limit = __double2float_ru(bound);
     bool found = false;
-    const PRay pr = pray_new(ray);
+    const PRay pr = pray_new(ray, asf(uni(__float_as_uint(Mg.coord_max))));
 
     float tn_root;
     const bool root_hit = active && node_box(Mg.root_min, Mg.root_max, ray, tn_root) && !(tn_root > limit);
@@ -172,11 +179,13 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
             const bool in = lane_in(curmask & alive);
             if (in) vc.nodes++;
             vc.wnodes++;
-            float t0, t1, t2, t3;
-            const bool h0 = RT_CHILD_TEST(n, 0, t0), h1 = RT_CHILD_TEST(n, 1, t1);
-            const bool h2 = RT_CHILD_TEST(n, 2, t2), h3 = RT_CHILD_TEST(n, 3, t3);
-            unsigned long long m0 = __ballot(in && h0 && !(t0 > limit)), m1 = __ballot(in && h1 && !(t1 > limit));
-            unsigned long long m2 = __ballot(in && h2 && !(t2 > limit)), m3 = __ballot(in && h3 && !(t3 > limit));
+            float t0, t1, t2, t3, f0, f1, f2, f3;
+            RT_CHILD_PAIR(n, 0, t0, f0, t1, f1);
+            RT_CHILD_PAIR(n, 2, t2, f2, t3, f3);
+            // the loop runs with every lane of the wave enabled, so a compare's lane mask is already the ballot
+            const unsigned long long inmask = curmask & alive;
+            unsigned long long m0 = box_lanes(t0, f0, limit) & inmask, m1 = box_lanes(t1, f1, limit) & inmask;
+            unsigned long long m2 = box_lanes(t2, f2, limit) & inmask, m3 = box_lanes(t3, f3, limit) & inmask;
             uint32_t r0 = n.ref[0], r1 = n.ref[1], r2 = n.ref[2], r3 = n.ref[3];
             if (r2 == RT_NO_CHILD) m2 = 0;
             if (r3 == RT_NO_CHILD) m3 = 0;

@@ -42,6 +42,8 @@ struct DMesh {
     const uint32_t* tri_nrm;   // [n_tris][3], mesh order
     const uint32_t* tri_uv;    // [n_tris][3] or null
     float root_min[3], root_max[3];   // the root's own box, f32 rounded outward
+    float coord_max;                  // largest |coordinate| of any box of the mesh (bounds the f32 slab rounding error)
+    uint32_t _pad0;
     uint32_t n_inner, n_tris, n_texcoords;
     uint32_t root_ref;         // 0 (inner node 0), or RT_LEAF_BIT | 0 when the root itself is a leaf
 };

@@ -152,7 +152,9 @@ DEV void trace_finish(const DScene& S, DLevel& L, uint32_t i, bool active, const
 
 // Closest hit of every ray of the level.  Rays whose hit will be lit are appended (in wave order) to the work list
 // of k_shadow, stored plane by plane: hs[k * stride + slot], k = 0..5.
-template <bool COUNT, bool PACKET>
+// BUDGET: the lane-by-lane walks give up after lp.budget_lane inner nodes (a separate variant: the bookkeeping costs
+// registers and time, and few scenes have rays that need it).
+template <bool COUNT, bool PACKET, bool BUDGET>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, uint32_t n, uint32_t* hitlist, double* hs, uint32_t stride,
                                                     DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -166,6 +168,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, 
     if (PACKET) {
         // the wave's rays are coherent (primary rays of an 8x8 pixel block) and walk the BVH together
         hit = cast_closest_packet(S, ray, active, c, vc);
+    } else if (active && !BUDGET) {
+        hit = cast_closest(S, ray, c, vc);
     } else if (active) {
         bool aborted = false;
         hit = cast_closest_seg(S, ray, c, vc, 0, 1, lp.budget_lane, aborted);

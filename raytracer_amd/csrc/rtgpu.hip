@@ -59,7 +59,8 @@ struct rt_ctx {
     DLevelCounts* h_lcounts = nullptr;                // pinned
     size_t n_lcounts = 0;
     hipStream_t side[RT_SIDE_STREAMS] = {nullptr, nullptr, nullptr, nullptr};   // shadow + lighting of level d runs on side[d % N]
-    LongParams long_params = {256u, 256u};            // walk budgets (inner nodes per lane / per wave) before a ray goes on the long-ray list; 0 = off
+    LongParams long_params = {0u, 256u};              // walk budgets (inner nodes per lane / per wave) before a ray goes on the long-ray list; 0 = off
+    bool serial = false;                              // RTGPU_SERIAL=1: everything on the main stream (profiling: kernels do not overlap)
     uint32_t long_below = 300000u;                  // ... applied to launches of fewer rays than this
     int count_visits = 0;                             // RTGPU_COUNT_VISITS: bit 0 k_trace, bit 1 k_shadow, bit 2 k_shade instrumented
     uint32_t n_lights = 0;
@@ -249,6 +250,10 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
     }
     if (!last[m.n_prims - 1]) return fail(c, RT_ERR_INVALID, "mesh BVH: leaf list does not end on a leaf boundary");
     box_of(0, out.root_min, out.root_max);
+    // every child box lies inside the root's (boxes are unions of their descendants'), up to the outward rounding
+    out.coord_max = 0.f;
+    for (int k = 0; k < 3; k++) out.coord_max = std::fmax(out.coord_max, std::fmax(std::fabs(out.root_min[k]), std::fabs(out.root_max[k])));
+    out.coord_max = out.coord_max * 1.000001f + 1e-30f;
     out.root_ref = m.nodes[0].count == 0 ? 0u : (RT_LEAF_BIT | m.nodes[0].right_or_first);
     out.n_inner = n_inner; out.n_tris = m.n_tris; out.n_texcoords = m.tri_uv ? m.n_texcoords : 0;
     int rc;
@@ -396,17 +401,19 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
         // launch the other waves hide a long walk, and cutting it up would only add work
         LongParams lp = c->long_params;
         if (n >= c->long_below) { lp.budget_lane = 0; lp.budget_wave = 0; }
-        hipStream_t side = c->side[depth % RT_SIDE_STREAMS];
+        hipStream_t side = c->serial ? s : c->side[depth % RT_SIDE_STREAMS];
         if (c->n_lights && lp.budget_wave) HIP_TRY(c, hipMemsetAsync(long_shadow, 0xFF, (size_t)RT_LONG_CAP * 8, s));
         const dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
         HIP_TRY(c, hipEventRecord(W.ev[LW_T0], s));
         // depth 0: primary rays, 8x8 pixel blocks per wave -> coherent packets; deeper rays are walked lane by lane
-        if (depth == 0) {
-            if (c->count_visits & 1) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters, lc, long_trace, lp);
-            else hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters, lc, long_trace, lp);
-        } else {
-            if (c->count_visits & 1) hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters, lc, long_trace, lp);
-            else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters, lc, long_trace, lp);
+        {
+            auto launch = [&](auto kern) {
+                hipLaunchKernelGGL(kern, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters, lc, long_trace, lp);
+            };
+            const bool cnt = (c->count_visits & 1) != 0;
+            if (depth == 0) { if (cnt) launch(k_trace<true, true, false>); else launch(k_trace<false, true, false>); }
+            else if (lp.budget_lane) { if (cnt) launch(k_trace<true, false, true>); else launch(k_trace<false, false, true>); }
+            else { if (cnt) launch(k_trace<true, false, false>); else launch(k_trace<false, false, false>); }
         }
         if (depth > 0 && lp.budget_lane) {
             if (c->count_visits & 1) hipLaunchKernelGGL(k_long_trace<true>, dim3(RT_LONG_BLOCKS), block, 0, s, c->dscene, c->levels[depth].lv, long_trace, hitlist, hs, n, c->dcounters, lc);
@@ -523,6 +530,7 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         c->count_visits = v == "1" ? 7 : v == "trace" ? 1 : v == "shadow" ? 2 : v == "shade" ? 4 : 0;
         if (const char* b = std::getenv("RTGPU_BUDGET_LANE")) c->long_params.budget_lane = (uint32_t)std::strtoul(b, nullptr, 10);
         if (const char* b = std::getenv("RTGPU_BUDGET_WAVE")) c->long_params.budget_wave = (uint32_t)std::strtoul(b, nullptr, 10);
+        c->serial = std::getenv("RTGPU_SERIAL") != nullptr;
         if (const char* b = std::getenv("RTGPU_BUDGET_BELOW")) c->long_below = (uint32_t)std::strtoul(b, nullptr, 10);
     }
     auto bail = [&](const char* what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); delete c; return RT_ERR_DEVICE; };
