@@ -215,16 +215,22 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* scene);
  *   stats_out   nullable */
 int rt_render(rt_ctx* ctx, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* stats_out);
 
-/* Image-space sharding for one-process-per-GPU runs.  The image is cut into
- * RT_TILE_W x RT_TILE_H pixel tiles, numbered row-major; shard s of n owns
- * tiles s, s+n, s+2n, ...  rt_shard_pixels returns the number of pixel slots
- * (whole tiles, edge tiles padded) shard s produces. */
+/* Image-space sharding for one-process-per-GPU runs (pixels are independent,
+ * scene.rs:239-242).  The image is cut into supertiles of S x S tiles of
+ * RT_TILE_W x RT_TILE_H pixels, S = rt_supertile() (4 unless the environment
+ * variable RTGPU_SUPER_SHIFT = log2 S says otherwise; one value per process).
+ * Supertiles are numbered row-major; shard s of n owns supertiles s, s+n,
+ * s+2n, ...  rt_shard_pixels returns the number of pixel slots (whole
+ * supertiles, edges padded) shard s produces. */
 #define RT_TILE_W 16
 #define RT_TILE_H 16
 int64_t rt_shard_pixels(int32_t vw, int32_t vh, uint32_t shard, uint32_t n_shards);
+uint32_t rt_supertile(void);
 
-/* Renders this shard's tiles into DEVICE memory, compact: slot k*256 + j is
- * pixel j (row-major inside the tile) of the shard's k-th tile.
+/* Renders this shard's supertiles into DEVICE memory, compact: the shard's
+ * k-th supertile is slots [k*S*S*256, (k+1)*S*S*256), tile by tile (row-major
+ * inside the supertile), 256 slots per tile: four 8x8 pixel blocks (left to
+ * right, top to bottom), each row-major.
  *   d_rgb   device pointer, rt_shard_pixels()*3 bytes
  *   d_ids   device pointer or NULL, rt_shard_pixels()*2 u32
  * The call returns after the kernels have completed. */

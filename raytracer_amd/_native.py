@@ -76,7 +76,7 @@ _host = None
 
 GPU_SYMBOLS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload", "rt_render",
-    "rt_shard_pixels", "rt_render_shard", "rt_detile", "rt_cast_rays",
+    "rt_shard_pixels", "rt_supertile", "rt_render_shard", "rt_detile", "rt_cast_rays",
 ]
 
 
@@ -96,6 +96,8 @@ def gpu():
         L.rt_render.restype = C.c_int
         L.rt_shard_pixels.argtypes = [C.c_int32, C.c_int32, C.c_uint32, C.c_uint32]
         L.rt_shard_pixels.restype = C.c_int64
+        L.rt_supertile.argtypes = []
+        L.rt_supertile.restype = C.c_uint32
         L.rt_render_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(RtStats)]
         L.rt_render_shard.restype = C.c_int
         L.rt_detile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64, C.c_uint32, C.c_void_p]

@@ -20,16 +20,23 @@
 #define RT_BLOCK RT_BLOCK_DIM
 #define RT_INACTIVE 0xFFFFFFFEu   // padding slot of an edge tile
 
+// The image is cut into supertiles of S x S tiles (S = 1 << super_shift) of 16 x 16 pixels, numbered row-major; a
+// shard owns supertiles shard, shard + n_shards, ...  A supertile is one compact run of S*S*256 slots, tile by tile
+// (row-major inside the supertile); tiles of an edge supertile that lie outside the image are all padding.
+// Neighbouring tiles share most of the BVH nodes their rays touch: handing a GPU whole 64 x 64 pixel blocks instead
+// of every n-th tile keeps those nodes in its L2.
 struct ShardMap {
-    uint32_t shard, n_shards, tiles_x, n_tiles;   // image tiles: 16 x 16 pixels, row-major
+    uint32_t shard, n_shards, supers_x, n_supers, super_shift;
     uint32_t row_major_out;                       // 1: write the frame row-major; 0: compact slot order
 };
 
 DEV bool slot_pixel(const ShardMap& m, int32_t vw, int32_t vh, uint32_t slot, int32_t& x, int32_t& y) {
-    uint32_t k = slot >> 8, j = slot & 255u;
-    uint64_t gid = (uint64_t)k * m.n_shards + m.shard;
-    if (gid >= m.n_tiles) return false;
-    uint32_t tx = (uint32_t)(gid % m.tiles_x), ty = (uint32_t)(gid / m.tiles_x);
+    const uint32_t sh = m.super_shift;
+    const uint32_t k = slot >> (8u + 2u * sh), t = (slot >> 8) & ((1u << (2u * sh)) - 1u), j = slot & 255u;
+    const uint64_t sid = (uint64_t)k * m.n_shards + m.shard;
+    if (sid >= m.n_supers) return false;
+    const uint32_t tx = ((uint32_t)(sid % m.supers_x) << sh) + (t & ((1u << sh) - 1u));
+    const uint32_t ty = ((uint32_t)(sid / m.supers_x) << sh) + (t >> sh);
     // the 64 slots of one wave cover an 8x8 pixel block (a compact ray packet); four blocks make the tile
     const uint32_t sub = j >> 6, w = j & 63u;
     x = (int32_t)(tx * 16u + (sub & 1u) * 8u + (w & 7u));
@@ -526,11 +533,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_ids_rowmajor(const DScene* Sp, con
 
 // Gathered compact shard buffers -> row-major image (rt_detile)
 __global__ __launch_bounds__(RT_BLOCK) void k_detile(const uint8_t* gathered, uint8_t* image, int32_t vw, int32_t vh, uint32_t n_shards,
-                                                     unsigned long long slots_per_shard, uint32_t elem_bytes, uint32_t tiles_x, uint32_t n_tiles) {
+                                                     unsigned long long slots_per_shard, uint32_t elem_bytes, ShardMap m) {
     const unsigned long long g = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
     const unsigned long long total = slots_per_shard * n_shards;
     if (g >= total) return;
-    ShardMap m; m.shard = (uint32_t)(g / slots_per_shard); m.n_shards = n_shards; m.tiles_x = tiles_x; m.n_tiles = n_tiles; m.row_major_out = 1;
+    m.shard = (uint32_t)(g / slots_per_shard);
     int32_t x, y;
     if (!slot_pixel(m, vw, vh, (uint32_t)(g % slots_per_shard), x, y)) return;
     const uint8_t* src = gathered + g * elem_bytes;

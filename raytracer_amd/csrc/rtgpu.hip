@@ -305,22 +305,33 @@ int ensure_buf(rt_ctx* c, void** p, size_t* cap, size_t bytes) {
     return RT_OK;
 }
 
+// tiles per supertile side as a shift; one value per process (RTGPU_SUPER_SHIFT=0..4 overrides the default 2)
+uint32_t super_shift() {
+    static const uint32_t v = [] {
+        const char* e = std::getenv("RTGPU_SUPER_SHIFT");
+        const long x = e ? std::strtol(e, nullptr, 10) : 2;
+        return (uint32_t)(x < 0 ? 0 : x > 4 ? 4 : x);
+    }();
+    return v;
+}
+
 ShardMap make_map(int32_t vw, int32_t vh, uint32_t shard, uint32_t n_shards, uint32_t row_major) {
     ShardMap m;
     m.shard = shard; m.n_shards = n_shards;
-    m.tiles_x = (uint32_t)((vw + RT_TILE_W - 1) / RT_TILE_W);
-    m.n_tiles = m.tiles_x * (uint32_t)((vh + RT_TILE_H - 1) / RT_TILE_H);
+    m.super_shift = super_shift();
+    const int32_t side = RT_TILE_W << m.super_shift;
+    m.supers_x = (uint32_t)((vw + side - 1) / side);
+    m.n_supers = m.supers_x * (uint32_t)((vh + side - 1) / side);
     m.row_major_out = row_major;
     return m;
 }
 
 uint64_t valid_pixels(const ShardMap& m, int32_t vw, int32_t vh) {
     uint64_t n = 0;
-    for (uint64_t gid = m.shard; gid < m.n_tiles; gid += m.n_shards) {
-        uint32_t tx = (uint32_t)(gid % m.tiles_x), ty = (uint32_t)(gid / m.tiles_x);
-        int32_t w = std::min<int32_t>(RT_TILE_W, vw - (int32_t)tx * RT_TILE_W);
-        int32_t h = std::min<int32_t>(RT_TILE_H, vh - (int32_t)ty * RT_TILE_H);
-        n += (uint64_t)w * (uint64_t)h;
+    const int32_t side = RT_TILE_W << m.super_shift;
+    for (uint64_t sid = m.shard; sid < m.n_supers; sid += m.n_shards) {
+        const int32_t sx = (int32_t)(sid % m.supers_x), sy = (int32_t)(sid / m.supers_x);
+        n += (uint64_t)std::min<int32_t>(side, vw - sx * side) * (uint64_t)std::min<int32_t>(side, vh - sy * side);
     }
     return n;
 }
@@ -508,10 +519,14 @@ extern "C" {
 
 int64_t rt_shard_pixels(int32_t vw, int32_t vh, uint32_t shard, uint32_t n_shards) {
     if (vw <= 0 || vh <= 0 || n_shards == 0 || shard >= n_shards) return -1;
-    const uint64_t tiles = (uint64_t)((vw + RT_TILE_W - 1) / RT_TILE_W) * (uint64_t)((vh + RT_TILE_H - 1) / RT_TILE_H);
-    const uint64_t mine = shard < tiles ? (tiles - shard + n_shards - 1) / n_shards : 0;
-    return (int64_t)(mine * RT_TILE_W * RT_TILE_H);
+    const uint32_t sh = super_shift();
+    const int32_t side = RT_TILE_W << sh;
+    const uint64_t supers = (uint64_t)((vw + side - 1) / side) * (uint64_t)((vh + side - 1) / side);
+    const uint64_t mine = shard < supers ? (supers - shard + n_shards - 1) / n_shards : 0;
+    return (int64_t)((mine << (2 * sh)) * RT_TILE_W * RT_TILE_H);
 }
+
+uint32_t rt_supertile(void) { return 1u << super_shift(); }
 
 int rt_ctx_create(int device_id, rt_ctx** out) {
     if (!out) { g_create_error = "rt_ctx_create: out is NULL"; return RT_ERR_INVALID; }
@@ -745,7 +760,7 @@ int rt_detile(rt_ctx* c, const void* d_gathered, uint32_t n_shards, int64_t slot
     const unsigned long long total = (unsigned long long)slots_per_shard * n_shards;
     if (total >= (1ull << 40)) return fail(c, RT_ERR_UNSUPPORTED, "rt_detile: too many slots");
     hipLaunchKernelGGL(k_detile, dim3((unsigned)((total + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, c->stream, static_cast<const uint8_t*>(d_gathered),
-                       static_cast<uint8_t*>(d_image), c->vw, c->vh, n_shards, (unsigned long long)slots_per_shard, elem_bytes, map.tiles_x, map.n_tiles);
+                       static_cast<uint8_t*>(d_image), c->vw, c->vh, n_shards, (unsigned long long)slots_per_shard, elem_bytes, map);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     return RT_OK;

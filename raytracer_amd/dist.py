@@ -1,7 +1,7 @@
 """Image-space sharding over one process per GPU.
 
 Pixels are independent (scene.rs:239-242), so the frame shards with no data-path
-exchange: every rank holds the whole scene, renders the 16x16 tiles
+exchange: every rank holds the whole scene, renders the supertiles (4x4 tiles of 16x16 pixels)
 `rank, rank + world, rank + 2*world, ...` into a compact device buffer
 (rt_render_shard) and the compact buffers are gathered to rank 0
 (torch.distributed.gather; RCCL over xGMI with the nccl backend), where one
@@ -12,15 +12,22 @@ import numpy as np
 TILE = 16
 
 
-def n_tiles(vw, vh):
-    return ((vw + TILE - 1) // TILE) * ((vh + TILE - 1) // TILE)
+def supertile():
+    """tiles per supertile side (the library's value: one per process)"""
+    from . import _native as N
+    return int(N.gpu().rt_supertile())
+
+
+def n_supertiles(vw, vh):
+    side = TILE * supertile()
+    return ((vw + side - 1) // side) * ((vh + side - 1) // side)
 
 
 def shard_slots(vw, vh, shard, n_shards):
-    """number of pixel slots (whole tiles) of one shard -- mirrors rt_shard_pixels"""
-    t = n_tiles(vw, vh)
+    """number of pixel slots (whole supertiles) of one shard -- mirrors rt_shard_pixels"""
+    t = n_supertiles(vw, vh)
     mine = (t - shard + n_shards - 1) // n_shards if shard < t else 0
-    return mine * TILE * TILE
+    return mine * (supertile() * TILE) ** 2
 
 
 def max_shard_slots(vw, vh, n_shards):
@@ -29,16 +36,20 @@ def max_shard_slots(vw, vh, n_shards):
 
 def shard_pixel_indices(vw, vh, shard, n_shards):
     """linear pixel index (y*vw + x) of every slot of a shard, -1 for the padding
-    slots of edge tiles -- the host-side statement of the device's slot map"""
+    slots of edge supertiles -- the host-side statement of the device's slot map"""
+    S = supertile()
+    per_super = S * S * 256
     slots = shard_slots(vw, vh, shard, n_shards)
-    k = np.arange(slots, dtype=np.int64) >> 8
-    j = np.arange(slots, dtype=np.int64) & 255
-    gid = k * n_shards + shard
-    tiles_x = (vw + TILE - 1) // TILE
+    slot = np.arange(slots, dtype=np.int64)
+    k, t, j = slot // per_super, (slot >> 8) % (S * S), slot & 255
+    sid = k * n_shards + shard
+    supers_x = (vw + TILE * S - 1) // (TILE * S)
+    tx = (sid % supers_x) * S + t % S
+    ty = (sid // supers_x) * S + t // S
     # the 64 slots of one wave cover an 8x8 pixel block; four blocks make the 16x16 tile
     sub, w = j >> 6, j & 63
-    x = (gid % tiles_x) * TILE + (sub & 1) * 8 + (w & 7)
-    y = (gid // tiles_x) * TILE + (sub >> 1) * 8 + (w >> 3)
+    x = tx * TILE + (sub & 1) * 8 + (w & 7)
+    y = ty * TILE + (sub >> 1) * 8 + (w >> 3)
     ok = (x < vw) & (y < vh)
     return np.where(ok, y * vw + x, -1)
 
@@ -54,6 +65,9 @@ def detile_host(gathered, vw, vh, n_shards, slots_per_shard, elem):
     return out.reshape(vh, vw, elem)
 
 
+_gather_bufs = {}
+
+
 def gather_frame(local, vw, vh, rank, world, detile):
     """Gathers every rank's compact shard buffer to rank 0 and assembles the frame.
 
@@ -67,9 +81,13 @@ def gather_frame(local, vw, vh, rank, world, detile):
     if world == 1:
         return detile(local)
     if rank == 0:
-        parts = [torch.empty_like(local) for _ in range(world)]
-        dist.gather(local, gather_list=parts, dst=0)
-        return detile(torch.cat(parts))
+        # one buffer, gathered into through per-rank views: no allocation churn and no concatenation copy per frame
+        key = (local.device, local.numel(), world)
+        buf = _gather_bufs.get(key)
+        if buf is None:
+            buf = _gather_bufs[key] = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+        dist.gather(local, gather_list=list(buf.chunk(world)), dst=0)
+        return detile(buf)
     dist.gather(local, gather_list=None, dst=0)
     return None
 
@@ -89,12 +107,76 @@ class ShardedRenderer:
         """-> (RtStats of this rank, frame tensor on rank 0 / None)"""
         import torch
         st = self.ctx.render_shard(self.rank, self.world, self.local.data_ptr())
-
-        def detile(gathered):
-            # the gather runs on torch's stream, rt_detile on the context's own: join them here
-            torch.cuda.current_stream(self.device).synchronize()
-            self.ctx.detile(gathered.data_ptr(), self.world, self.slots, 3, self.frame.data_ptr())
-            return self.frame
-
-        frame = gather_frame(self.local, self.vw, self.vh, self.rank, self.world, detile)
+        frame = gather_frame(self.local, self.vw, self.vh, self.rank, self.world, self.detile)
         return st, frame
+
+    def detile(self, gathered):
+        import torch
+        # the gather runs on torch's stream, rt_detile on the context's own: join them here
+        if torch.device(self.device).type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        self.ctx.detile(gathered.data_ptr(), self.world, self.slots, 3, self.frame.data_ptr())
+        return self.frame
+
+
+class FramePipeline:
+    """Several frames of a sequence in flight on one GPU (the reference's multi-frame workload is `--sequence`,
+    sdl/src/main.rs:70-95: independent frames, one after the other).
+
+    A frame is a chain of dependent launches with a count read-back per level; near the end of each launch only a
+    few long rays are left and most of the chip idles.  With `depth` contexts, each driven by its own host thread
+    (the library calls release the GIL), the next frame's work fills those gaps.  Frames are handed back in order;
+    the gather to rank 0 and the de-tile run on the calling thread, in frame order on every rank, so the collective
+    sequence is the same everywhere.
+    """
+
+    def __init__(self, make_context, rank, world, device, depth=2):
+        import queue
+        import threading
+        self.rank, self.world, self.device, self.depth = rank, world, device, depth
+        self.ctxs = [make_context() for _ in range(depth)]
+        self.renderers = [ShardedRenderer(c, rank, world, device) for c in self.ctxs]
+        self._go = [queue.Queue() for _ in range(depth)]
+        self._done = [queue.Queue() for _ in range(depth)]
+        self._threads = [threading.Thread(target=self._worker, args=(k,), daemon=True) for k in range(depth)]
+        for t in self._threads:
+            t.start()
+
+    def _worker(self, k):
+        r = self.renderers[k]
+        while True:
+            job = self._go[k].get()
+            if job is None:
+                return
+            try:
+                self._done[k].put(r.ctx.render_shard(r.rank, r.world, r.local.data_ptr()))
+            except Exception as e:  # handed to the caller of run()
+                self._done[k].put(e)
+
+    def run(self, n_frames, on_frame=None):
+        """Renders n_frames frames; on_frame(index, stats, frame_tensor_or_None) is called in frame order.
+        Returns the list of per-frame RtStats of this rank."""
+        stats = []
+        for f in range(min(self.depth, n_frames)):
+            self._go[f % self.depth].put(f)
+        for f in range(n_frames):
+            k = f % self.depth
+            st = self._done[k].get()
+            if isinstance(st, Exception):
+                raise st
+            r = self.renderers[k]
+            frame = gather_frame(r.local, r.vw, r.vh, self.rank, self.world, r.detile)
+            if on_frame is not None:
+                on_frame(f, st, frame)
+            stats.append(st)
+            if f + self.depth < n_frames:
+                self._go[k].put(f + self.depth)     # the slot's buffer is free again once its frame is gathered
+        return stats
+
+    def close(self):
+        for q in self._go:
+            q.put(None)
+        for t in self._threads:
+            t.join(timeout=10)
+        for c in self.ctxs:
+            c.close()

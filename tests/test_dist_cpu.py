@@ -71,3 +71,92 @@ def test_shard_map_partitions_the_image():
                 assert len(idx) == rd.shard_slots(vw, vh, s, n) <= rd.max_shard_slots(vw, vh, n)
                 np.add.at(seen, idx[idx >= 0], 1)
             assert (seen == 1).all()                        # every pixel in exactly one shard
+
+
+class _OracleCtx:
+    """Stands in for a GPU context on the CPU: the shard comes from the oracle, the de-tile from its host statement.
+    Frame f is rendered with the sphere row shifted by f, so frames differ and their order can be checked."""
+
+    def __init__(self, vw, vh):
+        self.vw, self.vh = vw, vh
+        self.frame_no = 0
+
+    def render_shard(self, rank, world, ptr):
+        import ctypes
+        import oracle
+        from raytracer_amd import dist as rd
+        from raytracer_amd import scenes
+        f = self.frame_no
+        s = scenes.small_mixed_scene(self.vw, self.vh, cells=4 + f)
+        slots = rd.max_shard_slots(self.vw, self.vh, world)
+        idx = rd.shard_pixel_indices(self.vw, self.vh, rank, world)
+        ok = idx >= 0
+        local = np.zeros((slots, 3), dtype=np.uint8)
+        rgb, _, st, _ = oracle.render(s, 1, pixels=idx[ok].astype(np.uint32), ids=False)
+        local[: len(idx)][ok] = rgb
+        ctypes.memmove(ptr, local.ctypes.data, local.nbytes)
+        return st
+
+    def detile(self, gptr, world, slots, elem, fptr):
+        import ctypes
+        from raytracer_amd import dist as rd
+        g = np.ctypeslib.as_array((ctypes.c_uint8 * (world * slots * elem)).from_address(gptr))
+        out = rd.detile_host(g, self.vw, self.vh, world, slots, elem)
+        ctypes.memmove(fptr, out.ctypes.data, out.nbytes)
+
+    def close(self):
+        pass
+
+
+def _pipeline_worker(rank, world, port, vw, vh, n_frames, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracer_amd import dist as rd
+        ctxs = []
+
+        def make():
+            ctxs.append(_OracleCtx(vw, vh))
+            return ctxs[-1]
+
+        pipe = rd.FramePipeline(make, rank, world, torch.device("cpu"), depth=2)
+        frames = []
+
+        def on_frame(f, st, frame):
+            if rank == 0:
+                frames.append(frame.numpy().reshape(vh, vw, 3).copy())
+
+        # the fake contexts learn their frame number from the slot: slot k renders frames k, k+2, ...
+        orig = [c.render_shard for c in ctxs]
+        for k, c in enumerate(ctxs):
+            def rs(rank_, world_, ptr, c=c, k=k, o=orig[k]):
+                st = o(rank_, world_, ptr)
+                c.frame_no += 2
+                return st
+            c.frame_no = k
+            c.render_shard = rs
+        stats = pipe.run(n_frames, on_frame)
+        pipe.close()
+        assert len(stats) == n_frames
+        if rank == 0:
+            np.save(out_path, np.stack(frames))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_frame_pipeline_keeps_frame_order(tmp_path):
+    """two frames in flight per rank, world size 2: every frame equals its single-process render, in order"""
+    sys.path.insert(0, ROOT)
+    import oracle
+    from raytracer_amd import scenes
+    vw, vh, n_frames = 40, 24, 5
+    port = 31500 + (os.getpid() % 2000)
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_pipeline_worker, args=(2, port, vw, vh, n_frames, out), nprocs=2, join=True)
+    frames = np.load(out)
+    assert frames.shape[0] == n_frames
+    for f in range(n_frames):
+        full, _, _, _ = oracle.render(scenes.small_mixed_scene(vw, vh, cells=4 + f), 1)
+        assert np.array_equal(frames[f], full), f

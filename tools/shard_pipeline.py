@@ -1,0 +1,39 @@
+"""Throughput of one GPU rendering shard 0 of N with 1..3 frames in flight (threads, one context each): how much of
+the per-frame tail the next frame's work fills in at small shard sizes."""
+import os
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import raytracer_amd as ra  # noqa: E402
+from raytracer_amd import dist as rd, scenes  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+s = scenes.synthetic_terrain_scene(3840, 2160)
+for depth in (1, 2, 3, 4):
+    ctxs = [ra.Context(0) for _ in range(depth)]
+    for c in ctxs:
+        c.upload(s)
+    bufs = [torch.zeros(rd.max_shard_slots(3840, 2160, n) * 3, dtype=torch.uint8, device="cuda:0") for _ in range(depth)]
+
+    def work(k, count):
+        for _ in range(count):
+            ctxs[k].render_shard(0, n, bufs[k].data_ptr())
+
+    for k in range(depth):
+        work(k, 2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=work, args=(k, frames)) for k in range(depth)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) * 1e3 / (frames * depth)
+    print(f"shard 0 of {n}, {depth} in flight: {dt:.3f} ms per frame", flush=True)
+    for c in ctxs:
+        c.close()
