@@ -94,10 +94,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    backend = os.environ.get("RT_DIST_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 path with ranks sharing a GPU
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     vw, vh = args.width, args.height
     t0 = time.perf_counter()
@@ -216,7 +222,7 @@ def main():
                 "workload": f"synthetic {info['n_tris']}-triangle height field ({args.cells}x{args.cells} cells) + 1 glass sphere + "
                             f"{args.lights} point lights with shadows, {vw}x{vh}, max_ray_depth 4 (BASELINE config 4)",
                 "resolution": [vw, vh], "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "lights": args.lights,
-                "parallelism": f"image tiles 16x16 interleaved over {world} GPU(s), gather to rank 0",
+                "parallelism": f"64x64-pixel supertiles interleaved over {world} GPU(s), gather to rank 0",
                 "frames_in_flight": depth,
             },
             "rays_per_frame": {"primary": rays[0], "reflect": rays[1], "transmit": rays[2], "shadow": rays[3], "total": rays_frame},

@@ -80,6 +80,15 @@ def gather_frame(local, vw, vh, rank, world, detile):
     import torch.distributed as dist
     if world == 1:
         return detile(local)
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # a backend that moves host memory only (rehearsals of the N > 1 path on one GPU): stage through the host
+        host = local.cpu()
+        if rank == 0:
+            parts = [torch.empty_like(host) for _ in range(world)]
+            dist.gather(host, gather_list=parts, dst=0)
+            return detile(torch.cat(parts).to(local.device))
+        dist.gather(host, gather_list=None, dst=0)
+        return None
     if rank == 0:
         # one buffer, gathered into through per-rank views: no allocation churn and no concatenation copy per frame
         key = (local.device, local.numel(), world)
