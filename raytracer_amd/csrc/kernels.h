@@ -123,9 +123,9 @@ DEV DShard* my_shard(DCounters* C) { return &C->shard[(blockIdx.x + blockIdx.y *
 // before its slowest ray is: with little other work on the chip (a deep level, a small shard) such rays set the
 // frame time.  A walk therefore gives up after a budget of inner nodes and puts its ray on the level's long-ray list;
 // a second kernel casts each listed ray again as RT_SEGS pieces in RT_SEGS neighbouring lanes (mesh_traverse_seg)
-// and merges their answers.  Lists are bounded: a ray that finds no free entry is simply walked to the end.
+// and merges their answers.  A level's lists hold every ray of the level (one entry per ray, or per ray and light
+// for shadow rays), so a ray that gives up always finds an entry.
 #define RT_SEGS 16             /* pieces per long ray = lanes per long ray */
-#define RT_LONG_CAP 262144     /* entries per long-ray list */
 #define RT_LONG_BLOCKS 512     /* grid of the long-ray kernels (they loop over the list) */
 struct LongParams { uint32_t budget_lane, budget_wave; };
 
@@ -181,9 +181,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, 
         bool aborted = false;
         hit = cast_closest_seg(S, ray, c, vc, 0, 1, lp.budget_lane, aborted);
         if (aborted) {
-            const unsigned long long e = atomicAdd(&LC->long_trace, 1ull);
-            if (e < RT_LONG_CAP) { longlist[e] = i; active = false; hit = false; }   // k_long_trace finishes this ray
-            else hit = cast_closest(S, ray, c, vc);
+            longlist[atomicAdd(&LC->long_trace, 1ull)] = i;   // k_long_trace finishes this ray
+            active = false; hit = false;
         }
     }
     trace_finish(S, L, i, active, ray, hit, c, hitlist, hs, stride, LC);
@@ -203,8 +202,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_long_trace(const DScene* Sp, DLevel L, const uint32_t* longlist, uint32_t* hitlist, double* hs,
                                                          uint32_t stride, DCounters* C, DLevelCounts* LC) {
     const DScene& S = *Sp;
-    const unsigned long long listed = LC->long_trace;
-    const uint32_t n_long = listed < RT_LONG_CAP ? (uint32_t)listed : RT_LONG_CAP;
+    const uint32_t n_long = (uint32_t)LC->long_trace;
     const uint32_t per_block = RT_BLOCK / RT_SEGS;
     Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
     for (uint32_t base = blockIdx.x * per_block; base < n_long; base += gridDim.x * per_block) {   // uniform per block
@@ -253,11 +251,11 @@ DEV Ray shadow_ray(const RT_GLOBAL DLight* Lt, const double* hs, uint32_t stride
 // share the light and walk neighbouring hit points, so their shadow rays are coherent.
 // occ[light * stride + ray] = 1 when shadowed.
 // (held to 64 VGPRs = 8 waves per SIMD: the walk waits on one scalar fetch per step, and waves hide that)
-#ifndef RT_SHADOW_WAVES
-#define RT_SHADOW_WAVES 8, 8
+#ifndef RT_SHADOW_ATTR
+#define RT_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHADOW_WAVES))) void k_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
+__global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
                                                                                                           DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
     const uint32_t h = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t li = blockIdx.y;
@@ -280,16 +278,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHA
             unsigned long long base = 0;
             if (lane_id() == 0) base = atomicAdd(&LC->long_shadow, (unsigned long long)cnt);
             base = ((unsigned long long)uni((uint32_t)(base >> 32)) << 32) | uni((uint32_t)base);
-            if (base + cnt <= RT_LONG_CAP) {
-                if (lane_in(unresolved)) {
-                    const unsigned long long e = base + __popcll(unresolved & ((1ull << lane_id()) - 1ull));
-                    longlist[2 * e] = hh; longlist[2 * e + 1] = li;
-                }
-            } else {
-                // no room: the wave walks its open rays to the end itself
-                unsigned long long none = 0;
-                const bool open = lane_in(unresolved);
-                if (cast_any_packet(S, ray, open, limited, dist, vc, 0, none) && open) occ[(size_t)li * stride + hitlist[hh]] = 1;
+            if (lane_in(unresolved)) {
+                const unsigned long long e = base + __popcll(unresolved & ((1ull << lane_id()) - 1ull));
+                longlist[2 * e] = hh; longlist[2 * e + 1] = li;
             }
         }
     }
@@ -302,14 +293,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHA
 }
 
 // The listed long shadow rays, RT_SEGS lanes each: any piece that finds a blocker sets the ray's byte.
-// Entries past the list's capacity were never written (their waves finished their rays themselves); the list is
-// filled with 0xFF before the frame, so an unwritten entry in range shows as light index 0xFFFFFFFF.
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_long_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
                                                           DCounters* C, const DLevelCounts* LC, const uint32_t* longlist) {
     const DScene& S = *Sp;
-    const unsigned long long listed = LC->long_shadow;
-    const uint32_t n_long = listed < RT_LONG_CAP ? (uint32_t)listed : RT_LONG_CAP;
+    const uint32_t n_long = (uint32_t)LC->long_shadow;
     const uint32_t per_block = RT_BLOCK / RT_SEGS;
     Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
     for (uint32_t base = blockIdx.x * per_block; base < n_long; base += gridDim.x * per_block) {

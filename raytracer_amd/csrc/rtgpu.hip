@@ -29,7 +29,7 @@ struct LevelWork {
     void* hitlist = nullptr; size_t hitlist_cap = 0;   // rays of the level whose hit is lit
     void* occ = nullptr; size_t occ_cap = 0;           // shadow results [light][ray]
     void* hs = nullptr; size_t hs_cap = 0;             // hit point + shadow-ray origin of every lit hit, 6 planes of doubles
-    void* long_trace = nullptr; size_t long_trace_cap = 0;     // long-ray lists (RT_LONG_CAP entries)
+    void* long_trace = nullptr; size_t long_trace_cap = 0;     // long-ray lists
     void* long_shadow = nullptr; size_t long_shadow_cap = 0;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // see LW_*
 };
@@ -343,8 +343,11 @@ int ensure_level_work(rt_ctx* c, size_t depth, size_t n) {
     int rc;
     if ((rc = ensure_buf(c, &W.hitlist, &W.hitlist_cap, n * 4)) != RT_OK) return rc;
     if (c->n_lights && (rc = ensure_buf(c, &W.occ, &W.occ_cap, n * c->n_lights)) != RT_OK) return rc;
-    if ((rc = ensure_buf(c, &W.long_trace, &W.long_trace_cap, (size_t)RT_LONG_CAP * 4)) != RT_OK) return rc;
-    if ((rc = ensure_buf(c, &W.long_shadow, &W.long_shadow_cap, (size_t)RT_LONG_CAP * 8)) != RT_OK) return rc;
+    // long-ray lists: one entry per ray (per ray and light), only for launches small enough to use them
+    if (n < c->long_below) {
+        if (c->long_params.budget_lane && (rc = ensure_buf(c, &W.long_trace, &W.long_trace_cap, n * 4)) != RT_OK) return rc;
+        if (c->long_params.budget_wave && c->n_lights && (rc = ensure_buf(c, &W.long_shadow, &W.long_shadow_cap, n * c->n_lights * 8)) != RT_OK) return rc;
+    }
     return ensure_buf(c, &W.hs, &W.hs_cap, n * 48);
 }
 
@@ -413,7 +416,6 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
         LongParams lp = c->long_params;
         if (n >= c->long_below) { lp.budget_lane = 0; lp.budget_wave = 0; }
         hipStream_t side = c->serial ? s : c->side[depth % RT_SIDE_STREAMS];
-        if (c->n_lights && lp.budget_wave) HIP_TRY(c, hipMemsetAsync(long_shadow, 0xFF, (size_t)RT_LONG_CAP * 8, s));
         const dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
         HIP_TRY(c, hipEventRecord(W.ev[LW_T0], s));
         // depth 0: primary rays, 8x8 pixel blocks per wave -> coherent packets; deeper rays are walked lane by lane
