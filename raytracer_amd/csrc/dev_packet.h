@@ -249,9 +249,11 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
     return any;
 }
 
-// Shadow cast for a whole wave (sun.rs:89, point.rs:91-92).  With a budget, a wave whose mesh walk runs long gives
-// up: `unresolved` then holds the lanes whose cast is still open (none of the objects after that mesh were tried
-// for them), to be cast again piecewise.
+// Shadow cast for a whole wave (sun.rs:89, point.rs:91-92).  "Blocked" is an OR over the objects, so their order is
+// free: the analytic objects go first (cheap, and every ray they block leaves the packets), the meshes last (after
+// the last walk nothing of the ray is needed any more, so it does not have to survive the walk in registers).
+// With a budget, a wave whose mesh walk runs long gives up: `unresolved` then holds the lanes whose cast is still
+// open, to be cast again piecewise.
 __device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bool limited, double dist, Visits& vc,
                                 uint32_t budget, unsigned long long& unresolved) {
     const uint32_t n = S.n_objects;
@@ -260,14 +262,7 @@ __device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bo
     unresolved = 0;
     for (uint32_t oi = 0; oi < n; oi++) {
         const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload);
-        if (kind == 3) {
-            MeshHit mh;
-            unsigned long long unres = 0;
-            if (packet_traverse<TRAV_ANY>(S.meshes[payload], ray, active && !blocked, limited ? dist : INFINITY, mh, vc, budget, unres)) blocked = true;
-            // every lane that is not blocked yet is cast again: the objects after this mesh were not tried for any of them
-            if (unres) { unresolved = __ballot(active && !blocked); return blocked; }
-            continue;
-        }
+        if (kind == 3) continue;
         if (active && !blocked) {
             double near; bool hit;
             if (kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
@@ -275,6 +270,16 @@ __device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bo
             else hit = box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
             if (hit && (!limited || near <= dist)) blocked = true;
         }
+    }
+    if (!__ballot(active && !blocked)) return blocked;
+    for (uint32_t oi = 0; oi < n; oi++) {
+        const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload);
+        if (kind != 3) continue;
+        MeshHit mh;
+        unsigned long long unres = 0;
+        if (packet_traverse<TRAV_ANY>(S.meshes[payload], ray, active && !blocked, limited ? dist : INFINITY, mh, vc, budget, unres)) blocked = true;
+        // every lane that is not blocked yet is cast again: the meshes after this one were not tried for any of them
+        if (unres) { unresolved = __ballot(active && !blocked); return blocked; }
         if (!__ballot(active && !blocked)) break;
     }
     return blocked;

@@ -262,8 +262,8 @@ __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene
     const DScene& S = *Sp;
     Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
     uint32_t cast = 0;
-    {
-        const bool have = h < (uint32_t)LC->hit_count;
+    const bool have = h < (uint32_t)LC->hit_count;
+    if (__ballot(have)) {   // the grid is sized for the worst case: most waves past the hit count have nothing to do
         const uint32_t hh = have ? h : 0;
         bool limited; double dist;
         const Ray ray = shadow_ray(gptr(S.lights) + li, hs, stride, hh, cast, limited, dist);
