@@ -219,6 +219,9 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
 
 // Scene::cast_ray_once for a whole wave (scene.rs:57-82): the object loop is uniform, meshes are walked as a
 // packet.  Every lane calls it; `active` lanes carry a ray.
+// FAR = false: the scene has no mesh whose material needs Hit::far, and the lane-by-lane two-hit walk is left out
+// of the kernel (it costs registers, hence waves per SIMD, even when it never runs).
+template <bool FAR>
 __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active, Closest& c, Visits& vc) {
     c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
     bool any = false;
@@ -230,7 +233,7 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
         double near = 0.; bool hit = false;
         if (kind == 3) {
             MeshHit mh;
-            if (need_far) {
+            if (FAR && need_far) {
                 if (active && mesh_traverse<TRAV_TWO>(S.meshes[payload], ray, INFINITY, mh, vc) && (!any || mh.t0 < c.t)) {
                     c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.n >= 2 ? mh.t1 : mh.t0; c.u = mh.u; c.v = mh.v; any = true;
                 }

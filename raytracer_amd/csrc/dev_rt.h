@@ -511,6 +511,8 @@ struct Closest { uint32_t obj, rank; double t, t2; float u, v; };
 // Scene::cast_ray_once (scene.rs:57-82): every object in scene order; the
 // stable sort by `near` keeps the lowest index among equals, i.e. a later
 // object must be strictly nearer to win.
+// FAR = false: the caller knows that no mesh of the scene needs Hit::far, and the two-hit walk is compiled out.
+template <bool FAR = true>
 __device__ bool cast_closest(const DScene& S, const Ray& ray, Closest& c, Visits& vc) {
     c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
     bool any = false;
@@ -525,7 +527,7 @@ __device__ bool cast_closest(const DScene& S, const Ray& ray, Closest& c, Visits
         else if (o.kind == 2) hit = box_near(gptr(S.boxes) + 6 * (size_t)o.payload, ray, near);
         else {
             MeshHit mh;
-            if (o.need_far) {
+            if (FAR && o.need_far) {
                 hit = mesh_traverse<TRAV_TWO>(S.meshes[o.payload], ray, INFINITY, mh, vc);
                 if (hit && (!any || mh.t0 < c.t)) {
                     c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.n >= 2 ? mh.t1 : mh.t0; c.u = mh.u; c.v = mh.v; any = true;
@@ -630,8 +632,11 @@ __device__ bool cast_any(const DScene& S, const Ray& ray, bool limited, double d
 // Rebuilds the full Hit of the closest object from the trace record
 __device__ void closest_hit_fill(const DScene& S, const Ray& ray, uint32_t obj, uint32_t rank, double t, double t2, float u, float v, Hit& h) {
     const RT_GLOBAL DObject* op = gptr(S.objects) + obj;
-    if (op->kind == 3) mesh_hit_fill(S.meshes[op->payload], ray, rank, t, t2, u, v, h);
-    else { Visits none; none.nodes = 0; none.tris = 0; none.wnodes = 0; none.wtris = 0; object_intersect(S, obj, ray, h, none); }   // never a mesh here
+    const uint32_t kind = op->kind, payload = op->payload;
+    if (kind == 3) mesh_hit_fill(S.meshes[payload], ray, rank, t, t2, u, v, h);
+    else if (kind == 0) sphere_intersect(gptr(S.spheres) + 4 * (size_t)payload, ray, h);
+    else if (kind == 1) plane_intersect(gptr(S.planes) + 8 * (size_t)payload, ray, h);
+    else box_intersect(ld3(gptr(S.boxes) + 6 * (size_t)payload), ld3(gptr(S.boxes) + 6 * (size_t)payload + 3), ray, h);
 }
 
 // ---------------------------------------------------------------- material.rs:119-141

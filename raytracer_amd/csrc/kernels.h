@@ -161,8 +161,14 @@ DEV void trace_finish(const DScene& S, DLevel& L, uint32_t i, bool active, const
 // of k_shadow, stored plane by plane: hs[k * stride + slot], k = 0..5.
 // BUDGET: the lane-by-lane walks give up after lp.budget_lane inner nodes (a separate variant: the bookkeeping costs
 // registers and time, and few scenes have rays that need it).
-template <bool COUNT, bool PACKET, bool BUDGET>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, uint32_t n, uint32_t* hitlist, double* hs, uint32_t stride,
+// FAR: see cast_closest_packet.
+// (asked to fit 4 waves per SIMD: the allocator then finds 118 registers enough, without spills, where it takes 156
+// when left alone)
+#ifndef RT_TRACE_ATTR
+#define RT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(4, 8)))
+#endif
+template <bool COUNT, bool PACKET, bool BUDGET, bool FAR = true>
+__global__ __launch_bounds__(RT_BLOCK) RT_TRACE_ATTR void k_trace(const DScene* Sp, DLevel L, uint32_t n, uint32_t* hitlist, double* hs, uint32_t stride,
                                                     DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     const DScene& S = *Sp;
@@ -174,9 +180,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(const DScene* Sp, DLevel L, 
     bool hit = false;
     if (PACKET) {
         // the wave's rays are coherent (primary rays of an 8x8 pixel block) and walk the BVH together
-        hit = cast_closest_packet(S, ray, active, c, vc);
+        hit = cast_closest_packet<FAR>(S, ray, active, c, vc);
     } else if (active && !BUDGET) {
-        hit = cast_closest(S, ray, c, vc);
+        hit = cast_closest<FAR>(S, ray, c, vc);
     } else if (active) {
         bool aborted = false;
         hit = cast_closest_seg(S, ray, c, vc, 0, 1, lp.budget_lane, aborted);

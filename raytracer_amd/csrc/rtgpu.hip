@@ -60,6 +60,8 @@ struct rt_ctx {
     size_t n_lcounts = 0;
     hipStream_t side[RT_SIDE_STREAMS] = {nullptr, nullptr, nullptr, nullptr};   // shadow + lighting of level d runs on side[d % N]
     LongParams long_params = {0u, 256u};              // walk budgets (inner nodes per lane / per wave) before a ray goes on the long-ray list; 0 = off
+    bool any_need_far = false;                        // some mesh's material needs Hit::far (transparency with ior == 1)
+    uint32_t packet_depth = 0;                        // levels 0..packet_depth trace their rays as wave packets
     bool serial = false;                              // RTGPU_SERIAL=1: everything on the main stream (profiling: kernels do not overlap)
     uint32_t long_below = 300000u;                  // ... applied to launches of fewer rays than this
     int count_visits = 0;                             // RTGPU_COUNT_VISITS: bit 0 k_trace, bit 1 k_shadow, bit 2 k_shade instrumented
@@ -424,9 +426,13 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
                 hipLaunchKernelGGL(kern, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters, lc, long_trace, lp);
             };
             const bool cnt = (c->count_visits & 1) != 0;
-            if (depth == 0) { if (cnt) launch(k_trace<true, true, false>); else launch(k_trace<false, true, false>); }
+            if (depth <= c->packet_depth) {
+                if (c->any_need_far) { if (cnt) launch(k_trace<true, true, false, true>); else launch(k_trace<false, true, false, true>); }
+                else { if (cnt) launch(k_trace<true, true, false, false>); else launch(k_trace<false, true, false, false>); }
+            }
             else if (lp.budget_lane) { if (cnt) launch(k_trace<true, false, true>); else launch(k_trace<false, false, true>); }
-            else { if (cnt) launch(k_trace<true, false, false>); else launch(k_trace<false, false, false>); }
+            else if (c->any_need_far) { if (cnt) launch(k_trace<true, false, false, true>); else launch(k_trace<false, false, false, true>); }
+            else { if (cnt) launch(k_trace<true, false, false, false>); else launch(k_trace<false, false, false, false>); }
         }
         if (depth > 0 && lp.budget_lane) {
             if (c->count_visits & 1) hipLaunchKernelGGL(k_long_trace<true>, dim3(RT_LONG_BLOCKS), block, 0, s, c->dscene, c->levels[depth].lv, long_trace, hitlist, hs, n, c->dcounters, lc);
@@ -548,6 +554,7 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         if (const char* b = std::getenv("RTGPU_BUDGET_LANE")) c->long_params.budget_lane = (uint32_t)std::strtoul(b, nullptr, 10);
         if (const char* b = std::getenv("RTGPU_BUDGET_WAVE")) c->long_params.budget_wave = (uint32_t)std::strtoul(b, nullptr, 10);
         c->serial = std::getenv("RTGPU_SERIAL") != nullptr;
+        if (const char* b = std::getenv("RTGPU_PACKET_DEPTH")) c->packet_depth = (uint32_t)std::strtoul(b, nullptr, 10);
         if (const char* b = std::getenv("RTGPU_BUDGET_BELOW")) c->long_below = (uint32_t)std::strtoul(b, nullptr, 10);
     }
     auto bail = [&](const char* what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); delete c; return RT_ERR_DEVICE; };
@@ -657,6 +664,7 @@ int rt_scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     if ((rc = upload(c, meshes.data(), meshes.size(), &H.meshes)) != RT_OK) return rc;
 
     std::vector<DObject> objs(d->n_objects);
+    bool any_far = false;
     for (uint32_t i = 0; i < d->n_objects; i++) {
         const rt_object& o = d->objects[i];
         if (o.material >= d->n_materials) return fail(c, RT_ERR_INVALID, "object: material index out of range");
@@ -666,6 +674,7 @@ int rt_scene_upload(rt_ctx* c, const rt_scene_desc* d) {
         const rt_material& m = d->materials[o.material];
         objs[i].kind = o.kind; objs[i].material = o.material; objs[i].payload = o.payload;
         objs[i].need_far = (o.kind == RT_OBJ_MESH && m.transparency > RT_EPSILON && m.ior == 1.) ? 1u : 0u;
+        if (objs[i].need_far) any_far = true;
     }
     if ((rc = upload(c, objs.data(), objs.size(), &H.objects)) != RT_OK) return rc;
 
@@ -701,6 +710,7 @@ int rt_scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     }
     HIP_TRY(c, hipMemcpy(c->dscene, &H, sizeof(DScene), hipMemcpyHostToDevice));
     c->vw = H.vw; c->vh = H.vh; c->max_depth = H.max_depth; c->n_lights = H.n_lights;
+    c->any_need_far = any_far;
     c->have_scene = true;
     c->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;
