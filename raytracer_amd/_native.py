@@ -149,6 +149,9 @@ def host():
             "rth_desc_info": ([vp, C.POINTER(C.c_uint32)], None),
             "rth_scene_render": ([vp, vp, C.c_int], C.c_int),
             "rth_scene_render_to": ([vp, C.c_char_p, C.c_int], C.c_int),
+            "rth_sdl_load": ([C.c_char_p, C.c_int, C.c_char_p, dbl, C.c_uint64], vp),
+            "rth_sdl_printed": ([], C.c_char_p),
+            "rth_scene_counts": ([vp, C.POINTER(u32)], None),
             "rth_write_png": ([C.c_char_p, u32, u32, vp], C.c_int),
             "rth_read_png": ([C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp], C.c_int),
         }
@@ -164,7 +167,7 @@ HOST_SYMBOLS = [
     "rth_last_error", "rth_scene_new", "rth_scene_free", "rth_set_camera", "rth_set_options", "rth_add_sphere",
     "rth_add_plane", "rth_add_aabb", "rth_mesh_new", "rth_mesh_from_obj", "rth_mesh_generate_sbvh", "rth_add_mesh",
     "rth_add_sun", "rth_add_point", "rth_scene_flatten", "rth_scene_save", "rth_desc_load", "rth_scene_render",
-    "rth_scene_render_to", "rth_write_png", "rth_read_png",
+    "rth_scene_render_to", "rth_write_png", "rth_read_png", "rth_sdl_load", "rth_sdl_printed",
 ]
 
 

@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "scene.hpp"
+#include "sdl.hpp"
 
 namespace rth {
 struct LoadedDesc;
@@ -210,5 +211,21 @@ int rth_read_png(const char* path, uint32_t* w, uint32_t* h, uint8_t* rgb) {
     if (rgb) std::memcpy(rgb, px.data(), px.size());
     return 0;
 }
+
+// The scene description language (sdl/src/main.rs:49-53: Interpreter::new(file).run()).  source_or_path is the script
+// text (is_path == 0) or a file name; t is the global `t`; seed feeds random().  On success returns a Scene (free it
+// with rth_scene_free) and, through rth_sdl_printed(), what print() wrote during this call.
+static thread_local std::string g_printed;
+Scene* rth_sdl_load(const char* source_or_path, int is_path, const char* base_dir, double t, uint64_t seed) {
+    SdlOptions opt; opt.t = t; opt.seed = seed; opt.base_dir = base_dir ? base_dir : "";
+    Scene* s = new Scene();
+    std::string err;
+    g_printed.clear();
+    const bool ok = is_path ? load_sdl_file(source_or_path, opt, *s, g_printed, err) : load_sdl(source_or_path, opt, *s, g_printed, err);
+    if (!ok) { delete s; g_err = err; return nullptr; }
+    return s;
+}
+const char* rth_sdl_printed() { return g_printed.c_str(); }
+void rth_scene_counts(Scene* s, uint32_t* out) { out[0] = (uint32_t)s->objects.size(); out[1] = (uint32_t)s->lights.size(); out[2] = (uint32_t)s->camera.vw; out[3] = (uint32_t)s->camera.vh; }
 
 }  // extern "C"

@@ -346,6 +346,48 @@ class LoadedScene:
         return N.host().rth_desc_get(self._h)
 
 
+class SdlScene:
+    """A scene built by the scene description language of the reference (sdl/src/main.rs:49-53).
+
+    source: the script text, or with path=True a file name.  t is the global `t` (the frame number of --sequence),
+    seed feeds random() (unseeded in the reference), base_dir resolves relative asset paths.
+    .printed holds what print() wrote."""
+
+    def __init__(self, source, path=False, base_dir=None, t=0.0, seed=1):
+        H = N.host()
+        self._h = H.rth_sdl_load(str(source).encode(), int(bool(path)), None if base_dir is None else str(base_dir).encode(),
+                                 float(t), int(seed))
+        if not self._h:
+            raise RuntimeError(N.host_error())
+        self.printed = H.rth_sdl_printed().decode(errors="replace")
+        out = (C.c_uint32 * 4)()
+        H.rth_scene_counts(self._h, out)
+        self.n_objects, self.n_lights, self.vw, self.vh = [int(x) for x in out]
+
+    def __del__(self):
+        try:
+            if self._h:
+                N.host().rth_scene_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_resolution(self, vw, vh):
+        N.host().rth_set_resolution(self._h, int(vw), int(vh))
+        self.vw, self.vh = int(vw), int(vh)
+        return self
+
+    def flatten(self):
+        p = N.host().rth_scene_flatten(self._h)
+        if not p:
+            raise RuntimeError(N.host_error())
+        return p
+
+    def save(self, path):
+        if N.host().rth_scene_save(self._h, str(path).encode()):
+            raise RuntimeError(N.host_error())
+
+
 def desc_info(desc_ptr):
     out = (C.c_uint32 * 8)()
     N.host().rth_desc_info(desc_ptr, out)

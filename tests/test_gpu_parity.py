@@ -290,3 +290,34 @@ def test_long_ray_lists_keep_parity(builder, args, monkeypatch):
     assert st.long_trace > 0 and st.long_shadow > 0
     assert_parity(rgb, ids, o_rgb, o_ids)
     assert ray_counts(st) == ray_counts(o_st)
+
+
+def test_sdl_script_renders_like_the_oracle(gpu_ctx):
+    """a scene written in the reference's scene description language, through the loader, on the GPU"""
+    src = """
+        camera { vw: 160, vh: 120, origin: <0, 1.5, 6>, pitch: -0.15, yaw: 0.0001, fov: 65 }
+        scene { max_ray_depth: 3, ambient: gray(30) }
+        skybox { type: "normal" }
+        sun { vector: <-0.4, -1, -0.6>, specular_power: 48 }
+        point_light { position: <2, 3, 2>, intensity: 4 }
+        plane { origin: <0, 0, 0>, material: { texture: checkerboard(gray(200), gray(60)), reflectiveness: 0.3 } }
+        let n = 7
+        for i in 0 to n {
+            let a = i / n * TAU
+            sphere {
+                position: <cos(a) * 2.5, 0.6, sin(a) * 2.5 - 1>,
+                radius: 0.5 + 0.1 * (i % 2),
+                material: { texture: solid(hsv(i / n * 360, 0.8, 1)), reflectiveness: 0.25 * (i % 3) },
+            }
+        }
+        sphere { position: <0, 1, -1>, radius: 1, material: { transparency: 0.7, reflectiveness: 0.4, ior: 1.45 } }
+        aabb { position: <0, 0.25, 2>, size: <0.6, 0.25, 0.3>, material: { texture: solid(rgb(240, 200, 40)), emissivity: 0.3 } }
+    """
+    s = ra.SdlScene(src)
+    assert (s.n_objects, s.n_lights) == (10, 2)
+    gpu_ctx.upload(s)
+    rgb, ids, st = gpu_ctx.render(ids=True)
+    o_rgb, o_ids, o_st, oc = oracle.render(s, 0)
+    assert_parity(rgb, ids, o_rgb, o_ids)
+    assert ray_counts(st) == ray_counts(o_st)
+    assert oc.would_panic == 0
