@@ -226,9 +226,10 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
     c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
     bool any = false;
     unsigned long long unres = 0;
-    const uint32_t n = S.n_objects;
+    const uint32_t n = S.n_linear;
     const RT_GLOBAL DObject* objs = gptr(S.objects);
-    for (uint32_t oi = 0; oi < n; oi++) {
+    for (uint32_t li_ = 0; li_ < n; li_++) {
+        const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload), need_far = uni(objs[oi].need_far);
         double near = 0.; bool hit = false;
         if (kind == 3) {
@@ -242,6 +243,7 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
             }
             continue;
         }
+        if (need_far & RT_IN_TLAS) continue;   // reached through the object tree below
         if (active) {
             if (kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
             else if (kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)payload, ray, near);
@@ -249,6 +251,7 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
         }
         if (hit && (!any || near < c.t)) { c.obj = oi; c.rank = RT_NONE; c.t = near; any = true; }
     }
+    if (S.n_tlas && active) any = tlas_closest(S, ray, c, any);
     return any;
 }
 
@@ -259,13 +262,14 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
 // open, to be cast again piecewise.
 __device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bool limited, double dist, Visits& vc,
                                 uint32_t budget, unsigned long long& unresolved) {
-    const uint32_t n = S.n_objects;
+    const uint32_t n = S.n_linear;
     const RT_GLOBAL DObject* objs = gptr(S.objects);
     bool blocked = false;
     unresolved = 0;
-    for (uint32_t oi = 0; oi < n; oi++) {
+    for (uint32_t li_ = 0; li_ < n; li_++) {
+        const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload);
-        if (kind == 3) continue;
+        if (kind == 3 || (uni(objs[oi].need_far) & RT_IN_TLAS)) continue;
         if (active && !blocked) {
             double near; bool hit;
             if (kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
@@ -274,8 +278,10 @@ __device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bo
             if (hit && (!limited || near <= dist)) blocked = true;
         }
     }
+    if (S.n_tlas && active && !blocked) blocked = tlas_any(S, ray, limited, dist);
     if (!__ballot(active && !blocked)) return blocked;
-    for (uint32_t oi = 0; oi < n; oi++) {
+    for (uint32_t li_ = 0; li_ < n; li_++) {
+        const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload);
         if (kind != 3) continue;
         MeshHit mh;

@@ -508,6 +508,56 @@ __device__ bool object_intersect(const DScene& S, uint32_t oi, const Ray& ray, H
 
 struct Closest { uint32_t obj, rank; double t, t2; float u, v; };
 
+// ---- object tree (DTlasNode).  The boxes cull exactly as long as the ray direction is a unit vector: the
+// reference's sphere test (sphere.rs:33-48) is only the geometric one for unit directions, and a ray reflected off
+// unnormalised mesh normals is not unit (mesh.rs:79-89).  For such a ray every box counts as hit and the walk
+// degenerates into the reference's linear scan.
+DEV bool tlas_culls(const Ray& ray) { return fabs(dot(ray.d, ray.d) - 1.) < 1e-9; }
+DEV bool tlas_object_near(const DScene& S, uint32_t oi, const Ray& ray, double& near) {
+    const RT_GLOBAL DObject* op = gptr(S.objects) + oi;
+    const uint32_t kind = op->kind, payload = op->payload;
+    if (kind == 0) return sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
+    return box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
+}
+// cast_ray_once over the tree's objects: nearest by `near`, ties to the lower object index (scene.rs:57-82); `c` may
+// already hold the best of the objects outside the tree
+__device__ bool tlas_closest(const DScene& S, const Ray& ray, Closest& c, bool any) {
+    const RT_GLOBAL DTlasNode* nodes = (const RT_GLOBAL DTlasNode*)S.tlas;
+    const bool cull = tlas_culls(ray);
+    const uint32_t n = S.n_tlas;
+    for (uint32_t i = 0; i < n;) {
+        const RT_GLOBAL DTlasNode* nd = nodes + i;
+        float tn;
+        if (cull && !(node_box(nd->bmin, nd->bmax, ray, tn) && !(any && tn > __double2float_ru(c.t)))) { i = nd->skip; continue; }
+        const uint32_t oi = nd->object;
+        if (oi != RT_NONE) {
+            double near;
+            if (tlas_object_near(S, oi, ray, near) && (!any || near < c.t || (near == c.t && oi < c.obj))) {
+                c.obj = oi; c.rank = RT_NONE; c.t = near; c.t2 = 0.; c.u = 0.f; c.v = 0.f; any = true;
+            }
+        }
+        i++;
+    }
+    return any;
+}
+__device__ bool tlas_any(const DScene& S, const Ray& ray, bool limited, double dist) {
+    const RT_GLOBAL DTlasNode* nodes = (const RT_GLOBAL DTlasNode*)S.tlas;
+    const bool cull = tlas_culls(ray);
+    const uint32_t n = S.n_tlas;
+    for (uint32_t i = 0; i < n;) {
+        const RT_GLOBAL DTlasNode* nd = nodes + i;
+        float tn;
+        if (cull && !node_box(nd->bmin, nd->bmax, ray, tn)) { i = nd->skip; continue; }
+        const uint32_t oi = nd->object;
+        if (oi != RT_NONE) {
+            double near;
+            if (tlas_object_near(S, oi, ray, near) && (!limited || near <= dist)) return true;
+        }
+        i++;
+    }
+    return false;
+}
+
 // Scene::cast_ray_once (scene.rs:57-82): every object in scene order; the
 // stable sort by `near` keeps the lowest index among equals, i.e. a later
 // object must be strictly nearer to win.
@@ -516,11 +566,13 @@ template <bool FAR = true>
 __device__ bool cast_closest(const DScene& S, const Ray& ray, Closest& c, Visits& vc) {
     c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
     bool any = false;
-    const uint32_t n = S.n_objects;
+    const uint32_t n = S.n_linear;
     const RT_GLOBAL DObject* objs = gptr(S.objects);
-    for (uint32_t oi = 0; oi < n; oi++) {
+    for (uint32_t li_ = 0; li_ < n; li_++) {
+        const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         struct { uint32_t kind, payload, need_far; } o;
         o.kind = objs[oi].kind; o.payload = objs[oi].payload; o.need_far = objs[oi].need_far;
+        if (o.kind != 3 && (o.need_far & RT_IN_TLAS)) continue;   // reached through the object tree below
         double near; bool hit;
         if (o.kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)o.payload, ray, near);
         else if (o.kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)o.payload, ray, near);
@@ -540,6 +592,7 @@ __device__ bool cast_closest(const DScene& S, const Ray& ray, Closest& c, Visits
         }
         if (hit && (!any || near < c.t)) { c.obj = oi; c.rank = RT_NONE; c.t = near; any = true; }
     }
+    if (S.n_tlas) any = tlas_closest(S, ray, c, any);
     return any;
 }
 
@@ -549,11 +602,13 @@ __device__ bool cast_closest_seg(const DScene& S, const Ray& ray, Closest& c, Vi
     c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
     bool any = false;
     aborted = false;
-    const uint32_t n = S.n_objects;
+    const uint32_t n = S.n_linear;
     const RT_GLOBAL DObject* objs = gptr(S.objects);
-    for (uint32_t oi = 0; oi < n; oi++) {
+    for (uint32_t li_ = 0; li_ < n; li_++) {
+        const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         struct { uint32_t kind, payload, need_far; } o;
         o.kind = objs[oi].kind; o.payload = objs[oi].payload; o.need_far = objs[oi].need_far;
+        if (o.kind != 3 && (o.need_far & RT_IN_TLAS)) continue;   // reached through the object tree below
         double near; bool hit;
         if (o.kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)o.payload, ray, near);
         else if (o.kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)o.payload, ray, near);
@@ -580,16 +635,19 @@ __device__ bool cast_closest_seg(const DScene& S, const Ray& ray, Closest& c, Vi
         }
         if (hit && (!any || near < c.t)) { c.obj = oi; c.rank = RT_NONE; c.t = near; any = true; }
     }
+    if (S.n_tlas) any = tlas_closest(S, ray, c, any);
     return any;
 }
 
 // cast_any with every mesh walk restricted to piece k of K
 __device__ bool cast_any_seg(const DScene& S, const Ray& ray, bool limited, double dist, Visits& vc, uint32_t k, uint32_t K) {
-    const uint32_t n = S.n_objects;
+    const uint32_t n = S.n_linear;
     const RT_GLOBAL DObject* objs = gptr(S.objects);
-    for (uint32_t oi = 0; oi < n; oi++) {
+    for (uint32_t li_ = 0; li_ < n; li_++) {
+        const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         struct { uint32_t kind, payload; } o;
         o.kind = objs[oi].kind; o.payload = objs[oi].payload;
+        if (o.kind != 3 && (objs[oi].need_far & RT_IN_TLAS)) continue;
         double near; bool hit;
         if (o.kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)o.payload, ray, near);
         else if (o.kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)o.payload, ray, near);
@@ -604,17 +662,19 @@ __device__ bool cast_any_seg(const DScene& S, const Ray& ray, bool limited, doub
         }
         if (hit && (!limited || near <= dist)) return true;
     }
-    return false;
+    return S.n_tlas != 0 && tlas_any(S, ray, limited, dist);
 }
 
 // Shadow casts.  sun.rs:89: any object the ray hits at all; point.rs:91-92:
 // the nearest hit has near <= dist, i.e. some object has near <= dist.
 __device__ bool cast_any(const DScene& S, const Ray& ray, bool limited, double dist, Visits& vc) {
-    const uint32_t n = S.n_objects;
+    const uint32_t n = S.n_linear;
     const RT_GLOBAL DObject* objs = gptr(S.objects);
-    for (uint32_t oi = 0; oi < n; oi++) {
+    for (uint32_t li_ = 0; li_ < n; li_++) {
+        const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         struct { uint32_t kind, payload; } o;
         o.kind = objs[oi].kind; o.payload = objs[oi].payload;
+        if (o.kind != 3 && (objs[oi].need_far & RT_IN_TLAS)) continue;
         double near; bool hit;
         if (o.kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)o.payload, ray, near);
         else if (o.kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)o.payload, ray, near);
@@ -626,7 +686,7 @@ __device__ bool cast_any(const DScene& S, const Ray& ray, bool limited, double d
         }
         if (hit && (!limited || near <= dist)) return true;
     }
-    return false;
+    return S.n_tlas != 0 && tlas_any(S, ray, limited, dist);
 }
 
 // Rebuilds the full Hit of the closest object from the trace record

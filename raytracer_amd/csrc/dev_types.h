@@ -50,7 +50,19 @@ struct DMesh {
 
 struct DObject {
     uint32_t kind, material, payload;
-    uint32_t need_far;         // mesh only: material needs Hit::far (transparency with ior == 1)
+    uint32_t need_far;         // mesh: 1 = the material needs Hit::far (transparency with ior == 1);
+                               // sphere / box: RT_IN_TLAS = reached through the object tree, skipped by the linear scans
+};
+#define RT_IN_TLAS 2u
+
+// Object tree over the bounded analytic objects (spheres, boxes) of a scene with many of them: the reference tests
+// every object per cast (scene.rs:57-82), which is 1728 sphere tests per ray in scenes/huge_grid.sdl.  Binary tree in
+// depth-first order with skip links, so a walk needs no stack: a node that is missed continues at `skip`, a node that
+// is entered at the next record.  Leaves hold one object.  Boxes are f32, rounded outward and inflated.
+struct DTlasNode {
+    float bmin[3], bmax[3];
+    uint32_t skip;             // next record when this subtree is skipped or done
+    uint32_t object;           // leaf: index into DScene::objects; inner node: RT_NONE
 };
 
 struct DMaterial {
@@ -86,6 +98,9 @@ struct DScene {
     const double* planes;           // [n][8] p0, n, uv_wrap (as double holding the f32 value), pad
     const double* boxes;            // [n][6] pos, half
     const DMesh* meshes;
+    const DTlasNode* tlas;          // null when the scene has few analytic objects
+    const uint32_t* linear;         // indices of the objects the casts scan one by one (all that are not in the tree)
+    uint32_t n_tlas, n_linear;
     const DMaterial* materials;
     const DLight* lights;
     uint32_t sky_kind, sky_rgb;     // packed solid colour

@@ -6,6 +6,7 @@
 // missing device is an error.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -305,6 +306,40 @@ int ensure_buf(rt_ctx* c, void** p, size_t* cap, size_t bytes) {
     if (hipMalloc(p, bytes) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipMalloc failed for an output buffer");
     *cap = bytes; c->work_bytes += bytes;
     return RT_OK;
+}
+
+// ---- object tree (DTlasNode): median split of the objects' boxes on the widest axis of their centres, emitted in
+// depth-first order with skip links
+struct TlasItem { double lo[3], hi[3]; uint32_t object; };
+float f32_down(double v) { float f = (float)v; return (double)f > v ? std::nextafterf(f, -INFINITY) : f; }
+float f32_up(double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, INFINITY) : f; }
+void build_tlas(std::vector<TlasItem>& items, size_t a, size_t b, std::vector<DTlasNode>& out) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = a; i < b; i++)
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], items[i].lo[k]); hi[k] = std::max(hi[k], items[i].hi[k]);
+            const double ctr = 0.5 * (items[i].lo[k] + items[i].hi[k]);
+            clo[k] = std::min(clo[k], ctr); chi[k] = std::max(chi[k], ctr);
+        }
+    const size_t me = out.size();
+    out.emplace_back();
+    for (int k = 0; k < 3; k++) {
+        // inflated: the exact object tests are f64 on the ray as given, the boxes only have to contain them
+        const double pad = 1e-5 * (std::fabs(lo[k]) + std::fabs(hi[k]) + (hi[k] - lo[k])) + 1e-30;
+        out[me].bmin[k] = f32_down(lo[k] - pad); out[me].bmax[k] = f32_up(hi[k] + pad);
+    }
+    if (b - a == 1) { out[me].object = items[a].object; out[me].skip = (uint32_t)out.size(); return; }
+    out[me].object = RT_NONE;
+    int axis = 0;
+    for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+    const size_t mid = a + (b - a) / 2;
+    std::nth_element(items.begin() + (long)a, items.begin() + (long)mid, items.begin() + (long)b, [axis](const TlasItem& x, const TlasItem& y) {
+        return x.lo[axis] + x.hi[axis] < y.lo[axis] + y.hi[axis];
+    });
+    build_tlas(items, a, mid, out);
+    build_tlas(items, mid, b, out);
+    out[me].skip = (uint32_t)out.size();
 }
 
 // tiles per supertile side as a shift; one value per process (RTGPU_SUPER_SHIFT=0..4 overrides the default 2)
@@ -676,7 +711,42 @@ int rt_scene_upload(rt_ctx* c, const rt_scene_desc* d) {
         objs[i].need_far = (o.kind == RT_OBJ_MESH && m.transparency > RT_EPSILON && m.ior == 1.) ? 1u : 0u;
         if (objs[i].need_far) any_far = true;
     }
+    // object tree over the spheres and boxes when there are enough of them to pay for it (RTGPU_TLAS_MIN, default 8)
+    {
+        std::vector<TlasItem> items;
+        for (uint32_t i = 0; i < d->n_objects; i++) {
+            const rt_object& o = d->objects[i];
+            TlasItem it; it.object = i;
+            bool finite = true;
+            if (o.kind == RT_OBJ_SPHERE) {
+                const rt_sphere& sp = d->spheres[o.payload];
+                for (int k = 0; k < 3; k++) { it.lo[k] = sp.c[k] - std::fabs(sp.r); it.hi[k] = sp.c[k] + std::fabs(sp.r); }
+            } else if (o.kind == RT_OBJ_BOX) {
+                const rt_box& b = d->boxes[o.payload];
+                for (int k = 0; k < 3; k++) { it.lo[k] = b.pos[k] - std::fabs(b.half[k]); it.hi[k] = b.pos[k] + std::fabs(b.half[k]); }
+            } else continue;
+            for (int k = 0; k < 3; k++) finite = finite && std::isfinite(it.lo[k]) && std::isfinite(it.hi[k]);
+            if (finite) items.push_back(it);   // an object with a NaN / infinite extent stays in the linear scan
+        }
+        uint32_t tlas_min = 8;
+        if (const char* e = std::getenv("RTGPU_TLAS_MIN")) tlas_min = (uint32_t)std::strtoul(e, nullptr, 10);
+        H.tlas = nullptr; H.n_tlas = 0;
+        if (items.size() >= std::max<uint32_t>(tlas_min, 2)) {
+            std::vector<DTlasNode> nodes;
+            nodes.reserve(items.size() * 2);
+            build_tlas(items, 0, items.size(), nodes);
+            for (const TlasItem& it : items) objs[it.object].need_far |= RT_IN_TLAS;
+            if ((rc = upload(c, nodes.data(), nodes.size(), &H.tlas)) != RT_OK) return rc;
+            H.n_tlas = (uint32_t)nodes.size();
+        }
+    }
     if ((rc = upload(c, objs.data(), objs.size(), &H.objects)) != RT_OK) return rc;
+    {
+        std::vector<uint32_t> linear;
+        for (uint32_t i = 0; i < d->n_objects; i++) if (objs[i].kind == RT_OBJ_MESH || !(objs[i].need_far & RT_IN_TLAS)) linear.push_back(i);
+        H.n_linear = (uint32_t)linear.size();
+        if ((rc = upload(c, linear.data(), linear.size(), &H.linear)) != RT_OK) return rc;
+    }
 
     std::vector<double> sph((size_t)d->n_spheres * 4), pln((size_t)d->n_planes * 8), bxs((size_t)d->n_boxes * 6);
     for (uint32_t i = 0; i < d->n_spheres; i++) { for (int k = 0; k < 3; k++) sph[4 * i + k] = d->spheres[i].c[k]; sph[4 * i + 3] = d->spheres[i].r; }

@@ -230,3 +230,32 @@ def reference_asset(name):
     """Path of a file under the reference checkout, or None where it is absent (the GPU box)."""
     p = os.path.join("/root/reference", name)
     return p if os.path.exists(p) else None
+
+
+def spheres_over_terrain_scene(vw=192, vh=108, n=4, cells=24, seed=3):
+    """n^3 spheres and a few boxes above a mirror-like height field: rays reflected off the mesh's interpolated,
+    unnormalised normals (mesh.rs:79-89) are not unit vectors, which is the case the reference's sphere test
+    (sphere.rs:33-48) treats differently from geometry -- and the device's object tree must not cull on."""
+    rng = np.random.default_rng(seed)
+    s = Scene()
+    s.set_camera(Camera(vw=vw, vh=vh, origin=(cells * 0.5, 7.0, cells + 6.0), yaw=0.02, pitch=-0.45, fov=60.))
+    s.set_options(max_ray_depth=3)
+    s.skybox_normal()
+    s.add_light(sdl_sun((-0.3, -1., -0.4)))
+    s.add_light(Point(position=(cells * 0.5, 9., cells * 0.5), intensity=40.))
+    mesh = Mesh.heightfield(cells, cells, cell=1.0, amplitude=1.5, base_freq=0.15, octaves=3, seed=seed,
+                            material=sdl_material(reflectiveness=0.7))
+    sdl_mesh(mesh, recenter=False)
+    s.add(mesh)
+    for i in range(n):
+        for j in range(n):
+            for k in range(n):
+                pos = (cells * (0.2 + 0.6 * i / max(n - 1, 1)) + float(rng.uniform(-.3, .3)), 3.0 + 1.4 * j,
+                       cells * (0.2 + 0.6 * k / max(n - 1, 1)) + float(rng.uniform(-.3, .3)))
+                col = (as_u8(40 + 200 * i / n), as_u8(40 + 200 * j / n), as_u8(40 + 200 * k / n))
+                if (i + j + k) % 5 == 0:
+                    s.add(Aabb(pos, (0.35, 0.3, 0.4), sdl_material(Texture.solid(col), reflectiveness=0.3)))
+                else:
+                    s.add(Sphere(pos, 0.45, sdl_material(Texture.solid(col), reflectiveness=0.4,
+                                                         transparency=0.5 if (i + k) % 3 == 0 else 0.)))
+    return s

@@ -52,6 +52,7 @@ def test_golden_fixture(gpu_ctx, name):
     (scenes.synthetic_terrain_scene, (256, 144, 48)),
     (scenes.huge_grid_scene, (192, 108, 5)),
     (scenes.terrain_scene, (256, 144, 24, 24)),
+    (scenes.spheres_over_terrain_scene, (192, 108, 4)),
 ])
 def test_against_oracle(gpu_ctx, builder, args):
     s = builder(*args)
