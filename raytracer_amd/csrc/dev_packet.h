@@ -243,7 +243,6 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
             }
             continue;
         }
-        if (need_far & RT_IN_TLAS) continue;   // reached through the object tree below
         if (active) {
             if (kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
             else if (kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)payload, ray, near);
@@ -269,7 +268,7 @@ __device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bo
     for (uint32_t li_ = 0; li_ < n; li_++) {
         const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload);
-        if (kind == 3 || (uni(objs[oi].need_far) & RT_IN_TLAS)) continue;
+        if (kind == 3) continue;
         if (active && !blocked) {
             double near; bool hit;
             if (kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);

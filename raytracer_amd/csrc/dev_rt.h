@@ -331,9 +331,6 @@ __device__ bool mesh_traverse_seg(const DMesh& M, const Ray& ray, double bound, 
     mh.n = 0; mh.t0 = bound; mh.t1 = bound; mh.r0 = 0;   // r0 = 0: a hit AT an outside bound never wins the tie
     float tn_root;
     uint32_t steps = 0;
-#ifdef RT_EXP_NOTRAV
-    if (MODE == TRAV_ANY) return false;
-#endif
     if (!node_box(M.root_min, M.root_max, ray, tn_root)) return false;
 
     int sp = 0;
@@ -406,9 +403,6 @@ __device__ bool mesh_traverse_seg(const DMesh& M, const Ray& ray, double bound, 
             const uint32_t last = T.last;
             double t; float u, v;
             vc.tris++;
-#ifdef RT_EXP_NOTRI
-            if (MODE != TRAV_ANY)
-#endif
             if (tri_test(T, ray, t, u, v)) {
                 if (MODE == TRAV_ANY) {
                     if (t <= bound) return true;
@@ -572,7 +566,6 @@ __device__ bool cast_closest(const DScene& S, const Ray& ray, Closest& c, Visits
         const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         struct { uint32_t kind, payload, need_far; } o;
         o.kind = objs[oi].kind; o.payload = objs[oi].payload; o.need_far = objs[oi].need_far;
-        if (o.kind != 3 && (o.need_far & RT_IN_TLAS)) continue;   // reached through the object tree below
         double near; bool hit;
         if (o.kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)o.payload, ray, near);
         else if (o.kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)o.payload, ray, near);
@@ -608,7 +601,6 @@ __device__ bool cast_closest_seg(const DScene& S, const Ray& ray, Closest& c, Vi
         const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         struct { uint32_t kind, payload, need_far; } o;
         o.kind = objs[oi].kind; o.payload = objs[oi].payload; o.need_far = objs[oi].need_far;
-        if (o.kind != 3 && (o.need_far & RT_IN_TLAS)) continue;   // reached through the object tree below
         double near; bool hit;
         if (o.kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)o.payload, ray, near);
         else if (o.kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)o.payload, ray, near);
@@ -647,7 +639,6 @@ __device__ bool cast_any_seg(const DScene& S, const Ray& ray, bool limited, doub
         const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         struct { uint32_t kind, payload; } o;
         o.kind = objs[oi].kind; o.payload = objs[oi].payload;
-        if (o.kind != 3 && (objs[oi].need_far & RT_IN_TLAS)) continue;
         double near; bool hit;
         if (o.kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)o.payload, ray, near);
         else if (o.kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)o.payload, ray, near);
@@ -674,7 +665,6 @@ __device__ bool cast_any(const DScene& S, const Ray& ray, bool limited, double d
         const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         struct { uint32_t kind, payload; } o;
         o.kind = objs[oi].kind; o.payload = objs[oi].payload;
-        if (o.kind != 3 && (objs[oi].need_far & RT_IN_TLAS)) continue;
         double near; bool hit;
         if (o.kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)o.payload, ray, near);
         else if (o.kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)o.payload, ray, near);
