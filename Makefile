@@ -8,7 +8,7 @@ ARCH    ?= gfx950
 
 GPU_SRC  := raytracer_amd/csrc/rtgpu.hip
 GPU_HDR  := raytracer_amd/csrc/kernels.h raytracer_amd/csrc/dev_packet.h raytracer_amd/csrc/dev_rt.h raytracer_amd/csrc/dev_types.h include/rtgpu.h
-HOST_SRC := raytracer_amd/host/mesh.cpp raytracer_amd/host/scene.cpp raytracer_amd/host/png.cpp raytracer_amd/host/sdl.cpp raytracer_amd/host/capi.cpp
+HOST_SRC := raytracer_amd/host/mesh.cpp raytracer_amd/host/scene.cpp raytracer_amd/host/png.cpp raytracer_amd/host/jpeg.cpp raytracer_amd/host/sdl.cpp raytracer_amd/host/capi.cpp
 HOST_HDR := raytracer_amd/host/scene.hpp raytracer_amd/host/sdl.hpp raytracer_amd/host/rmath.hpp include/rtgpu.h
 
 all: raytracer_amd/librtgpu.so raytracer_amd/librthost.so oracle/liboracle.so

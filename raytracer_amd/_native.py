@@ -154,6 +154,7 @@ def host():
             "rth_scene_counts": ([vp, C.POINTER(u32)], None),
             "rth_write_png": ([C.c_char_p, u32, u32, vp], C.c_int),
             "rth_read_png": ([C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp], C.c_int),
+            "rth_read_image": ([C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp], C.c_int),
         }
         for name, (args, res) in sig.items():
             fn = getattr(L, name)

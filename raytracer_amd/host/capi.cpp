@@ -211,6 +211,13 @@ int rth_read_png(const char* path, uint32_t* w, uint32_t* h, uint8_t* rgb) {
     if (rgb) std::memcpy(rgb, px.data(), px.size());
     return 0;
 }
+// PNG or baseline JPEG, told apart by content; same two-call protocol
+int rth_read_image(const char* path, uint32_t* w, uint32_t* h, uint8_t* rgb) {
+    std::vector<uint8_t> px; std::string e;
+    if (!read_image(path, *w, *h, px, e)) return fail(e);
+    if (rgb) std::memcpy(rgb, px.data(), px.size());
+    return 0;
+}
 
 // The scene description language (sdl/src/main.rs:49-53: Interpreter::new(file).run()).  source_or_path is the script
 // text (is_path == 0) or a file name; t is the global `t`; seed feeds random().  On success returns a Scene (free it

@@ -149,5 +149,7 @@ void make_star_atlas(uint32_t cell, uint64_t seed, std::vector<uint8_t>& rgb);
 
 bool write_png(const std::string& path, uint32_t w, uint32_t h, const uint8_t* rgb, std::string& err);
 bool read_png(const std::string& path, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgb, std::string& err);
+bool read_jpeg(const std::string& path, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgb, std::string& err);   // baseline only
+bool read_image(const std::string& path, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgb, std::string& err);  // PNG or JPEG, by content
 
 }  // namespace rth

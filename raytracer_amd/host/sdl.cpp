@@ -887,9 +887,7 @@ class Interp {
         std::vector<uint8_t> rgb;
         std::string err;
         const std::string path = resolve(file);
-        if (path.size() >= 4 && (path.compare(path.size() - 4, 4, ".jpg") == 0 || (path.size() >= 5 && path.compare(path.size() - 5, 5, ".jpeg") == 0)))
-            fail("generic image error: " + file + ": JPEG decoding is not available here, convert the file to PNG");
-        if (!read_png(path, w, h, rgb, err)) fail("generic image error: " + file + ": " + err);
+        if (!read_image(path, w, h, rgb, err)) fail("generic image error: " + file + ": " + err);
         auto t = std::make_shared<Texture>(Texture::image(w, h, rgb.data()));
         images_[file] = t;
         return t;

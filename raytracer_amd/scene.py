@@ -401,6 +401,17 @@ def write_png(path, rgb):
         raise RuntimeError(N.host_error())
 
 
+def read_image(path):
+    """PNG or baseline JPEG (told apart by content) -> (h, w, 3) uint8"""
+    w, h = C.c_uint32(), C.c_uint32()
+    if N.host().rth_read_image(str(path).encode(), C.byref(w), C.byref(h), None):
+        raise RuntimeError(N.host_error())
+    out = np.empty((h.value, w.value, 3), dtype=np.uint8)
+    if N.host().rth_read_image(str(path).encode(), C.byref(w), C.byref(h), out.ctypes.data):
+        raise RuntimeError(N.host_error())
+    return out
+
+
 def read_png(path):
     w, h = C.c_uint32(), C.c_uint32()
     if N.host().rth_read_png(str(path).encode(), C.byref(w), C.byref(h), None):

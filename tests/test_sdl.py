@@ -158,5 +158,21 @@ def test_reference_scenes_that_need_only_shipped_assets_load():
     # a stale scene file: the interpreter has required `tris` since; same refusal as the reference's
     with pytest.raises(RuntimeError, match="property tris must be specified"):
         ra.SdlScene(f"{REF}/scenes/icosahedron.sdl", path=True, base_dir=REF)
-    with pytest.raises(RuntimeError, match="JPEG"):
-        ra.SdlScene(f"{REF}/scenes/refraction.sdl", path=True, base_dir=REF)
+    with pytest.raises(RuntimeError, match="progressive"):     # assets/earth.jpg is a progressive JPEG
+        ra.SdlScene('sphere { position: <0, 0, -3>, radius: 1, material: { texture: image("assets/earth.jpg") } }', base_dir=REF)
+
+
+@needs_ref
+def test_config_2_and_3_scene_files_with_their_real_cubemap():
+    """scenes/refraction.sdl and scenes/fedora.sdl unmodified (cubemap assets/storforsen_4.jpg through the JPEG
+    reader, assets/fedora.obj + fedora.png) render exactly as the hand-built scenes given the same decoded assets"""
+    cm = ra.read_image(REF + "/assets/storforsen_4.jpg")
+    vw, vh = 128, 72
+    cases = [("refraction", lambda: scenes.refraction_scene(vw, vh, cubemap=cm)),
+             ("fedora", lambda: scenes.fedora_scene(REF + "/assets/fedora.obj", ra.read_image(REF + "/assets/fedora.png"), vw, vh, cubemap=cm))]
+    for name, hand in cases:
+        s = ra.SdlScene(f"{REF}/scenes/{name}.sdl", path=True, base_dir=REF).set_resolution(vw, vh)
+        a, _, sa, _ = oracle.render(s, 0)
+        b, _, sb, _ = oracle.render(hand(), 0)
+        assert sa.rays == sb.rays, name
+        assert np.array_equal(a, b), name
