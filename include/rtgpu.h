@@ -161,14 +161,18 @@ typedef struct rt_stats {
     uint64_t rays_primary, rays_reflect, rays_transmit, rays_shadow;
     uint64_t rays_per_level[8];   /* trace_ray invocations per depth        */
     double   ms_upload;           /* last rt_scene_upload                   */
-    double   ms_render;           /* kernels of the last frame (HIP events) */
+    double   ms_render;           /* first to last kernel of the last frame (HIP events on the main stream) */
     double   ms_total;            /* render + copy-out wall time            */
-    double   ms_trace, ms_shadow, ms_shade, ms_resolve;   /* per-phase kernel time, summed over depths */
+    /* Per phase, the launches' own durations summed over depths (HIP events on the stream each phase runs on):
+     * closest-hit casts; shadow casts; spawn + lighting; the final fold.  The phases of a frame overlap (the shadow
+     * casts of a level run beside the trace of the next), so these add up to more than ms_render. */
+    double   ms_trace, ms_shadow, ms_shade, ms_resolve;
     uint64_t device_bytes;        /* device memory held by the context      */
     /* Work the traversal kernels really did: inner BVH nodes visited (two box
      * tests each) and triangles tested.  Only counted when the context was
      * created with RTGPU_COUNT_VISITS=1 in the environment (instrumented kernel
-     * variants, slower); 0 otherwise. */
+     * variants, slower; "trace" / "shadow" / "shade" instrument one phase only);
+     * 0 otherwise. */
     uint64_t nodes_visited, tris_tested;
     /* the same for the wave-coherent packet walks, counted once per wave (a wave visits a node / tests a
      * triangle when any of its 64 rays needs it) */

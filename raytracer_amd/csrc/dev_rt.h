@@ -524,7 +524,7 @@ __device__ bool tlas_closest(const DScene& S, const Ray& ray, Closest& c, bool a
         float tn;
         if (cull && !(node_box(nd->bmin, nd->bmax, ray, tn) && !(any && tn > __double2float_ru(c.t)))) { i = nd->skip; continue; }
         const uint32_t oi = nd->object;
-        if (oi != RT_NONE) {
+        if (!(oi & RT_TLAS_INNER)) {
             double near;
             if (tlas_object_near(S, oi, ray, near) && (!any || near < c.t || (near == c.t && oi < c.obj))) {
                 c.obj = oi; c.rank = RT_NONE; c.t = near; c.t2 = 0.; c.u = 0.f; c.v = 0.f; any = true;
@@ -543,13 +543,63 @@ __device__ bool tlas_any(const DScene& S, const Ray& ray, bool limited, double d
         float tn;
         if (cull && !node_box(nd->bmin, nd->bmax, ray, tn)) { i = nd->skip; continue; }
         const uint32_t oi = nd->object;
-        if (oi != RT_NONE) {
+        if (!(oi & RT_TLAS_INNER)) {
             double near;
             if (tlas_object_near(S, oi, ray, near) && (!limited || near <= dist)) return true;
         }
         i++;
     }
     return false;
+}
+// tlas_closest for the kernels that own a per-lane stack (the lane-by-lane trace kernels): nearer child first, so
+// that the nearest object is found early and the boxes behind it are never entered.  Same answer as the skip-link
+// walk: every object whose box the ray enters before the best distance is tested, ties go to the lower index.
+__device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c, bool any) {
+    const RT_GLOBAL DTlasNode* nodes = (const RT_GLOBAL DTlasNode*)S.tlas;
+    const bool cull = tlas_culls(ray);
+    const float INF = __uint_as_float(0x7F800000u);
+    int sp = 0;
+    volatile unsigned long long spill[RT_MAX_STACK - RT_LDS_STACK];
+    float limit = any ? __double2float_ru(c.t) : INF;
+    float tn_root = -INF;
+    if (cull && !(node_box(nodes[0].bmin, nodes[0].bmax, ray, tn_root) && !(tn_root > limit))) return any;
+    uint32_t cur = 0;
+    while (true) {
+        const uint32_t info = nodes[cur].object;
+        if (!(info & RT_TLAS_INNER)) {
+            double near;
+            if (tlas_object_near(S, info, ray, near) && (!any || near < c.t || (near == c.t && info < c.obj))) {
+                c.obj = info; c.rank = RT_NONE; c.t = near; c.t2 = 0.; c.u = 0.f; c.v = 0.f; any = true;
+                limit = __double2float_ru(near);
+            }
+            cur = RT_POP;
+        } else {
+            const uint32_t l = cur + 1, r = info & ~RT_TLAS_INNER;
+            float tl = -INF, tr = -INF;
+            bool hl = true, hr = true;
+            if (cull) {
+                hl = node_box(nodes[l].bmin, nodes[l].bmax, ray, tl) && !(tl > limit);
+                hr = node_box(nodes[r].bmin, nodes[r].bmax, ray, tr) && !(tr > limit);
+            }
+            if (hl && hr) {
+                const bool left_first = !(tr < tl);
+                const uint32_t far = left_first ? r : l;
+                const float tfar = left_first ? tr : tl;
+                if (sp >= RT_MAX_STACK) return any;   // cannot happen: a median-split tree over < 2^31 objects is < 32 deep
+                RT_STACK_PUSH(far, tfar);
+                cur = left_first ? l : r;
+            } else cur = hl ? l : hr ? r : RT_POP;
+        }
+        if (cur == RT_POP) {
+            while (sp > 0) {
+                uint2 e;
+                RT_STACK_POP(e);
+                if (!(__uint_as_float(e.y) > limit)) { cur = e.x; break; }
+            }
+            if (cur == RT_POP) break;
+        }
+    }
+    return any;
 }
 
 // Scene::cast_ray_once (scene.rs:57-82): every object in scene order; the
@@ -585,7 +635,7 @@ __device__ bool cast_closest(const DScene& S, const Ray& ray, Closest& c, Visits
         }
         if (hit && (!any || near < c.t)) { c.obj = oi; c.rank = RT_NONE; c.t = near; any = true; }
     }
-    if (S.n_tlas) any = tlas_closest(S, ray, c, any);
+    if (S.n_tlas) any = tlas_closest_ordered(S, ray, c, any);
     return any;
 }
 
@@ -627,7 +677,7 @@ __device__ bool cast_closest_seg(const DScene& S, const Ray& ray, Closest& c, Vi
         }
         if (hit && (!any || near < c.t)) { c.obj = oi; c.rank = RT_NONE; c.t = near; any = true; }
     }
-    if (S.n_tlas) any = tlas_closest(S, ray, c, any);
+    if (S.n_tlas) any = tlas_closest_ordered(S, ray, c, any);
     return any;
 }
 

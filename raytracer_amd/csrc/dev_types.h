@@ -62,8 +62,10 @@ struct DObject {
 struct DTlasNode {
     float bmin[3], bmax[3];
     uint32_t skip;             // next record when this subtree is skipped or done
-    uint32_t object;           // leaf: index into DScene::objects; inner node: RT_NONE
+    uint32_t object;           // leaf: index into DScene::objects; inner node: RT_TLAS_INNER | index of its second child
+                               // (the first child is the next record)
 };
+#define RT_TLAS_INNER 0x80000000u
 
 struct DMaterial {
     uint32_t tex_kind;

@@ -330,7 +330,6 @@ void build_tlas(std::vector<TlasItem>& items, size_t a, size_t b, std::vector<DT
         out[me].bmin[k] = f32_down(lo[k] - pad); out[me].bmax[k] = f32_up(hi[k] + pad);
     }
     if (b - a == 1) { out[me].object = items[a].object; out[me].skip = (uint32_t)out.size(); return; }
-    out[me].object = RT_NONE;
     int axis = 0;
     for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
     const size_t mid = a + (b - a) / 2;
@@ -338,6 +337,7 @@ void build_tlas(std::vector<TlasItem>& items, size_t a, size_t b, std::vector<DT
         return x.lo[axis] + x.hi[axis] < y.lo[axis] + y.hi[axis];
     });
     build_tlas(items, a, mid, out);
+    out[me].object = RT_TLAS_INNER | (uint32_t)out.size();
     build_tlas(items, mid, b, out);
     out[me].skip = (uint32_t)out.size();
 }

@@ -36,3 +36,9 @@ if "terrain_small" in which: check("terrain_small", scenes.synthetic_terrain_sce
 if "terrain_med" in which: check("terrain_med", scenes.synthetic_terrain_scene(1280, 720, cells=256), sample=20000)
 if "terrain_full" in which: check("terrain_full", scenes.synthetic_terrain_scene(3840, 2160, cells=708), sample=2000)
 if "huge_grid" in which: check("huge_grid", scenes.huge_grid_scene(480, 270, n=6))
+# the BASELINE configurations at their full sizes (oracle on a pixel sample)
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+if "config2" in which: check("config2 refraction 1920x1080", scenes.refraction_scene(1920, 1080), sample=20000)
+if "config3" in which: check("config3 fedora 3840x2160", ra.LoadedScene(os.path.join(GOLDEN, "fedora_192x108.rtscene")).set_resolution(3840, 2160), sample=20000)
+if "config5a" in which: check("config5 huge_grid 7680x4320", scenes.huge_grid_scene(7680, 4320, n=12), sample=3000)
+if "config5b" in which: check("config5 terrain 7680x4320", scenes.terrain_scene(7680, 4320), sample=20000)

@@ -13,7 +13,7 @@ from raytracer_amd import dist as rd, scenes  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 s = scenes.synthetic_terrain_scene(3840, 2160)
-for depth in (1, 2, 3, 4):
+for depth in [int(x) for x in os.environ.get("DEPTHS", "1,2,3,4").split(",")]:
     ctxs = [ra.Context(0) for _ in range(depth)]
     for c in ctxs:
         c.upload(s)
