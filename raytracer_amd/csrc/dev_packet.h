@@ -16,7 +16,7 @@
 #define RT_CONST __attribute__((address_space(4)))   /* constant address space: uniform addresses load through the scalar cache */
 typedef unsigned int __attribute__((ext_vector_type(4))) rt_u4;
 
-#define RT_PSTACK 64   /* packet stack entries per wave (16 bytes each) */
+#define RT_PSTACK 64   /* packet stack entries per wave (16 bytes each); upload refuses a mesh whose walk could need more */
 __shared__ rt_u4 rt_pstack[(RT_BLOCK_DIM / 64) * RT_PSTACK];
 
 DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -35,6 +35,23 @@ DEV UNode load_unode(const DNode* nodes, uint32_t idx) {
     const RT_CONST rt_u4* p = (const RT_CONST rt_u4*)(nodes + idx);
     UNode n;
     n.minx = p[0]; n.miny = p[1]; n.minz = p[2]; n.maxx = p[3]; n.maxy = p[4]; n.maxz = p[5]; n.ref = p[6];
+    return n;
+}
+// The same record through the vector memory path: lanes 0..6 fetch 16 bytes each, and the values are handed to the
+// scalar registers lane by lane.
+DEV rt_u4 lane_u4(const rt_u4& v, int lane) {
+    rt_u4 r;
+    r.x = (uint32_t)__builtin_amdgcn_readlane((int)v.x, lane); r.y = (uint32_t)__builtin_amdgcn_readlane((int)v.y, lane);
+    r.z = (uint32_t)__builtin_amdgcn_readlane((int)v.z, lane); r.w = (uint32_t)__builtin_amdgcn_readlane((int)v.w, lane);
+    return r;
+}
+DEV UNode load_unode_v(const DNode* nodes, uint32_t idx) {
+    const uint32_t l = threadIdx.x & 63u;
+    rt_u4 v = {0u, 0u, 0u, 0u};
+    if (l < 8) v = ((const RT_GLOBAL rt_u4*)(nodes + idx))[l];
+    UNode n;
+    n.minx = lane_u4(v, 0); n.miny = lane_u4(v, 1); n.minz = lane_u4(v, 2);
+    n.maxx = lane_u4(v, 3); n.maxy = lane_u4(v, 4); n.maxz = lane_u4(v, 5); n.ref = lane_u4(v, 6);
     return n;
 }
 DEV TriData load_utri(const DTri* tris, uint32_t rank) {
@@ -217,6 +234,191 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
     return MODE == TRAV_ANY ? found : (mh.n > 0);
 }
 
+// ---- shadow casts with the triangle tests set aside
+//
+// In the walk above a leaf costs the wave one full triangle test per triangle, whatever the number of lanes whose
+// ray entered the leaf -- on a terrain mesh about 8 of 64, so most of the arithmetic of a shadow cast runs on idle
+// lanes.  A shadow cast only asks WHETHER something blocks the ray, so the tests can wait: the walk notes (lane,
+// leaf) pairs in an LDS queue, and whenever 64 pairs have gathered, every lane of the wave takes one pair, reads
+// that ray (parked in LDS at the start) and the leaf's triangles (vector loads), and runs the same exact test.  A
+// hit clears the owner's bound word; owners look at their word after each batch and leave the packet.
+// What is tested is unchanged (each ray against the triangles of the leaves its box chain reached, until the ray is
+// known to be blocked), only later.
+#ifndef RT_ANY_LOAD_NODE
+#define RT_ANY_LOAD_NODE load_unode
+#endif
+#define RT_QCAP 320                       /* 63 pairs left over + the up to 4 x 64 one node step can add */
+#define RT_PACKET_MAX_PRIMS (1u << 26)    /* a pair is (leaf's first triangle << 6) | lane in one word */
+#define RT_PWAVES (RT_BLOCK_DIM / 64)
+__shared__ double rt_qray[RT_PWAVES * 6 * 64];                // [wave][o.x o.y o.z d.x d.y d.z][lane]
+__shared__ unsigned long long rt_qbound[RT_PWAVES * 64];      // bits of the lane's distance limit, + 1; 0 = blocked / no ray
+__shared__ uint32_t rt_qpair[RT_PWAVES * RT_QCAP];
+
+DEV bool in_mask(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }   // this lane's bit, for free
+DEV uint32_t lanes_below(unsigned long long mask) {   // set bits of mask below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+DEV void wave_lds_sync() {   // LDS accesses of one wave execute in order; this only keeps the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// A wave-uniform stack in three vector registers: entry i lives in lane i (v_writelane / v_readlane with a uniform
+// lane number), so a push or pop is three register moves -- no LDS traffic and no wait on the way to the next
+// node fetch.  64 entries; upload refuses a mesh whose walk could need more.
+extern "C" __device__ int rt_writelane_i32(int value, int lane, int into) __asm("llvm.amdgcn.writelane.i32");
+struct RStack {
+    int ref, lo, hi;
+    uint32_t sp;
+    DEV void push(uint32_t r, unsigned long long m) {
+        ref = rt_writelane_i32((int)r, (int)sp, ref);
+        lo = rt_writelane_i32((int)(uint32_t)m, (int)sp, lo);
+        hi = rt_writelane_i32((int)(uint32_t)(m >> 32), (int)sp, hi);
+        ++sp;
+    }
+    DEV unsigned long long top_mask() const {
+        return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(hi, (int)sp - 1) << 32) | (uint32_t)__builtin_amdgcn_readlane(lo, (int)sp - 1);
+    }
+    DEV uint32_t top_ref() const { return (uint32_t)__builtin_amdgcn_readlane(ref, (int)sp - 1); }
+};
+
+// Parks the wave's rays.  bound: hits with t <= bound block the ray (t > 0 always, so the bit patterns order like the
+// values; a NaN or non-positive bound can never be met).
+DEV void park_rays(const Ray& ray, bool active, double bound) {
+    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    double* qr = rt_qray + w * 6 * 64;
+    qr[l] = ray.o.x; qr[64 + l] = ray.o.y; qr[128 + l] = ray.o.z;
+    qr[192 + l] = ray.d.x; qr[256 + l] = ray.d.y; qr[320 + l] = ray.d.z;
+    unsigned long long b = 0;
+    if (active) b = bound > 0. ? (unsigned long long)__double_as_longlong(bound) + 1ull : 1ull;
+    rt_qbound[w * 64 + l] = b;
+    wave_lds_sync();
+}
+DEV bool parked_blocked() { return rt_qbound[threadIdx.x] == 0; }   // (one word per thread of the block)
+
+// One batch: lane k takes pair base + k (k < cnt).
+__device__ void test_pairs(const DTri* tris, uint32_t base, uint32_t cnt, Visits& vc) {
+    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const double* qr = rt_qray + w * 6 * 64;
+    unsigned long long* qb = rt_qbound + w * 64;
+    wave_lds_sync();
+    vc.wtris++;
+    if (l < cnt) {
+        const uint32_t pair = rt_qpair[w * RT_QCAP + base + l];
+        uint32_t rank = pair >> 6;
+        const uint32_t owner = pair & 63u;
+        const unsigned long long b = qb[owner];
+        if (b != 0) {
+            const D3 ro = d3(qr[owner], qr[64 + owner], qr[128 + owner]);
+            const D3 rd = d3(qr[192 + owner], qr[256 + owner], qr[320 + owner]);
+            while (true) {
+                const TriData T = tri_load(gptr(tris) + rank);
+                double t; float u, v;
+                vc.tris++;
+                if (tri_test_od(T, ro, rd, t, u, v) && (unsigned long long)__double_as_longlong(t) < b) { qb[owner] = 0; break; }
+                if (T.last) break;
+                ++rank;
+            }
+        }
+    }
+    wave_lds_sync();
+}
+
+// The shadow walk of one mesh for the parked rays.  Every lane of the wave must call it.  Lanes found blocked have
+// their bound word cleared.  budget / unresolved as in packet_traverse.
+__device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget, unsigned long long& unresolved) {
+    unresolved = 0;
+    uint32_t steps = 0;
+    const DNode* nodes = uni_ptr(Mg.nodes);
+    const DTri* tris = uni_ptr(Mg.tris);
+    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    uint32_t* q = rt_qpair + w * RT_QCAP;
+    PRay pr; float limit; unsigned long long alive;
+    {
+        const double* qr = rt_qray + w * 6 * 64;
+        const unsigned long long b = rt_qbound[w * 64 + l];
+        const Ray ray = ray_new(d3(qr[l], qr[64 + l], qr[128 + l]), d3(qr[192 + l], qr[256 + l], qr[320 + l]));
+        pr = pray_new(ray, asf(uni(__float_as_uint(Mg.coord_max))));
+        // b - 1 = the bits of the bound, or 0 (a bound that cannot be met: the box distance limit 0 is then as good as any)
+        limit = b > 1 ? __double2float_ru(__longlong_as_double((long long)(b - 1ull))) : 0.f;
+        float tn_root;
+        const bool root_hit = b != 0 && node_box(Mg.root_min, Mg.root_max, ray, tn_root) && !(tn_root > limit);
+        alive = __ballot(root_hit);
+    }
+    // The box-test constants are not carried across a batch of triangle tests (which wants every register it can
+    // get): they are worked out again from the parked ray afterwards.
+#define RT_REDO_CONSTANTS()                                                                                              \
+    do {                                                                                                                 \
+        const double* qr_ = rt_qray + w * 6 * 64;                                                                        \
+        const unsigned long long b_ = rt_qbound[w * 64 + l];                                                             \
+        const D3 o_ = d3(qr_[l], qr_[64 + l], qr_[128 + l]), d_ = d3(qr_[192 + l], qr_[256 + l], qr_[320 + l]);          \
+        const float B_ = asf(uni(__float_as_uint(Mg.coord_max)));                                                        \
+        pray_axis(o_.x, 1. / d_.x, B_, pr.mx, pr.cminx, pr.cmaxx);                                                       \
+        pray_axis(o_.y, 1. / d_.y, B_, pr.my, pr.cminy, pr.cmaxy);                                                       \
+        pray_axis(o_.z, 1. / d_.z, B_, pr.mz, pr.cminz, pr.cmaxz);                                                       \
+        limit = b_ > 1 ? __double2float_ru(__longlong_as_double((long long)(b_ - 1ull))) : 0.f;                          \
+    } while (0)
+    if (!alive) return;
+    const uint32_t root = uni(Mg.root_ref);
+    uint32_t qn = 0;
+    RStack st; st.ref = 0; st.lo = 0; st.hi = 0; st.sp = 0;
+    bool finishing = false;   // nothing left to walk: test what is queued, then leave
+    if (root & RT_LEAF_BIT) {
+        // a mesh of one leaf
+        if (in_mask(alive)) q[lanes_below(alive)] = ((root & ~RT_LEAF_BIT) << 6) | l;
+        qn = (uint32_t)__popcll(alive);
+        finishing = true;
+    } else st.push(root, alive);
+
+    // a child some lane entered: a leaf's (lane, leaf) pairs go on the queue, an inner node on the stack
+#define RT_CHILD_ENTERED(r_, m_)                                                                    \
+    if (m_) {                                                                                       \
+        if ((r_) & RT_LEAF_BIT) {                                                                   \
+            if (in_mask(m_)) q[qn + lanes_below(m_)] = (((r_) & ~RT_LEAF_BIT) << 6) | l;            \
+            qn += (uint32_t)__popcll(m_);                                                           \
+        } else st.push((r_), (m_));                                                                 \
+    }
+
+    while (true) {
+        // (the one place where triangles are tested, so that the kernel holds that code once)
+        if (qn >= 64 || (finishing && qn)) {
+            const uint32_t cnt = qn < 64 ? qn : 64;
+            qn -= cnt;
+            test_pairs(tris, qn, cnt, vc);
+            alive &= ~__ballot(parked_blocked());
+            if (!alive) break;
+            if (!finishing && qn < 64) RT_REDO_CONSTANTS();
+            continue;
+        }
+        if (finishing) break;
+        if (st.sp == 0) { finishing = true; continue; }
+        const unsigned long long inmask = st.top_mask() & alive;
+        if (!inmask) { --st.sp; continue; }   // everybody who wanted this node has been blocked since
+        const uint32_t cur = st.top_ref();
+        --st.sp;
+        if (budget && ++steps > budget) { finishing = true; unresolved = 1; continue; }
+        const UNode n = RT_ANY_LOAD_NODE(nodes, cur);
+        if (in_mask(inmask)) vc.nodes++;
+        vc.wnodes++;
+        float t0, t1, t2, t3, f0, f1, f2, f3;
+        RT_CHILD_PAIR(n, 0, t0, f0, t1, f1);
+        RT_CHILD_PAIR(n, 2, t2, f2, t3, f3);
+        // the loop runs with every lane of the wave enabled, so a compare's lane mask is already the ballot
+        const unsigned long long m0 = box_lanes(t0, f0, limit) & inmask, m1 = box_lanes(t1, f1, limit) & inmask;
+        unsigned long long m2 = box_lanes(t2, f2, limit) & inmask, m3 = box_lanes(t3, f3, limit) & inmask;
+        if (n.ref[2] == RT_NO_CHILD) m2 = 0;
+        if (n.ref[3] == RT_NO_CHILD) m3 = 0;
+        RT_CHILD_ENTERED(n.ref[3], m3)
+        RT_CHILD_ENTERED(n.ref[2], m2)
+        RT_CHILD_ENTERED(n.ref[1], m1)
+        RT_CHILD_ENTERED(n.ref[0], m0)   // pushed last: walked first
+    }
+    if (unresolved) unresolved = alive;   // the walk ran out of budget: the lanes that are still open
+#undef RT_CHILD_ENTERED
+#undef RT_REDO_CONSTANTS
+    if (qn) test_pairs(tris, 0, qn, vc);
+}
+
 // Scene::cast_ray_once for a whole wave (scene.rs:57-82): the object loop is uniform, meshes are walked as a
 // packet.  Every lane calls it; `active` lanes carry a ray.
 // FAR = false: the scene has no mesh whose material needs Hit::far, and the lane-by-lane two-hit walk is left out
@@ -279,16 +481,18 @@ __device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bo
     }
     if (S.n_tlas && active && !blocked) blocked = tlas_any(S, ray, limited, dist);
     if (!__ballot(active && !blocked)) return blocked;
+    const bool open = active && !blocked;   // the lanes whose cast the meshes decide
+    park_rays(ray, open, limited ? dist : INFINITY);
     for (uint32_t li_ = 0; li_ < n; li_++) {
         const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload);
         if (kind != 3) continue;
-        MeshHit mh;
         unsigned long long unres = 0;
-        if (packet_traverse<TRAV_ANY>(S.meshes[payload], ray, active && !blocked, limited ? dist : INFINITY, mh, vc, budget, unres)) blocked = true;
+        packet_any_deferred(S.meshes[payload], vc, budget, unres);
+        const unsigned long long still = __ballot(open && !parked_blocked());
         // every lane that is not blocked yet is cast again: the meshes after this one were not tried for any of them
-        if (unres) { unresolved = __ballot(active && !blocked); return blocked; }
-        if (!__ballot(active && !blocked)) break;
+        if (unres) { unresolved = still; break; }
+        if (!still) break;
     }
-    return blocked;
+    return blocked || (open && parked_blocked());
 }

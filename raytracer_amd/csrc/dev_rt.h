@@ -248,21 +248,24 @@ DEV TriData tri_load(TP T) {
     r.orig = (uint32_t)w; r.last = (uint32_t)(w >> 32);
     return r;
 }
-DEV bool tri_test(const TriData& T, const Ray& ray, double& t_out, float& u_out, float& v_out) {
+DEV bool tri_test_od(const TriData& T, const D3& ro, const D3& rd, double& t_out, float& u_out, float& v_out) {
     const D3 v0 = T.v0, edge1 = T.e1, edge2 = T.e2;
-    D3 h = cross(ray.d, edge2);
+    D3 h = cross(rd, edge2);
     double a = dot(edge1, h);
     if (a > -RT_EPSILON && a < RT_EPSILON) return false;
     double f = 1. / a;
-    D3 s = ray.o - v0;
+    D3 s = ro - v0;
     double u = f * dot(s, h);
     if (!(u >= 0.0 && u <= 1.0)) return false;
     D3 q = cross(s, edge1);
-    double v = f * dot(ray.d, q);
+    double v = f * dot(rd, q);
     if (v < 0.0 || u + v > 1.0) return false;
     double t = f * dot(edge2, q);
     if (t > RT_EPSILON) { t_out = t; u_out = (float)u; v_out = (float)v; return true; }
     return false;
+}
+DEV bool tri_test(const TriData& T, const Ray& ray, double& t_out, float& u_out, float& v_out) {
+    return tri_test_od(T, ray.o, ray.d, t_out, u_out, v_out);
 }
 
 struct MeshHit { double t0, t1; uint32_t r0; float u, v; uint32_t n; };   // n = hits kept (0, 1, 2)

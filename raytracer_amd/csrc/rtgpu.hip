@@ -196,14 +196,17 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
     std::vector<DNode> nodes;
     nodes.reserve(n_inner / 2 + 1);
     std::vector<uint8_t> last(m.n_prims, 0);
+    uint32_t pstack_need = 0;
     for (uint32_t i = 0; i < NN; i++)
         if (seen[i] && m.nodes[i].count != 0) last[m.nodes[i].right_or_first + m.nodes[i].count - 1] = 1;
     if (m.nodes[0].count == 0) {
-        std::vector<std::pair<uint32_t, uint32_t>> work;   // (reference node, device node index)
+        // (reference node, device node index, entries on the packet walk's stack when the node is entered)
+        struct Work { uint32_t ri, di, held; };
+        std::vector<Work> work;
         nodes.emplace_back();
-        work.push_back({0u, 0u});
+        work.push_back({0u, 0u, 0u});
         while (!work.empty()) {
-            auto [ri, di] = work.back(); work.pop_back();
+            auto [ri, di, held] = work.back(); work.pop_back();
             uint32_t kids[4]; int nk = 2;
             kids[0] = ri + 1; kids[1] = m.nodes[ri].right_or_first;
             while (nk < 4) {
@@ -236,11 +239,18 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
                 else { child_dev[k] = (uint32_t)nodes.size(); nodes.emplace_back(); dn.ref[k] = child_dev[k]; }
             }
             nodes[di] = dn;
+            // the packet walks stack every child that was entered and take the top one
+            pstack_need = std::max(pstack_need, held + (uint32_t)nk);
             for (int k = nk - 1; k >= 0; k--)
-                if (m.nodes[kids[k]].count == 0) work.push_back({kids[k], child_dev[k]});
+                if (m.nodes[kids[k]].count == 0) work.push_back({kids[k], child_dev[k], held + (uint32_t)nk - 1u});
         }
     }
     n_inner = (uint32_t)nodes.size();
+    if (pstack_need > RT_PSTACK)
+        return fail(c, RT_ERR_UNSUPPORTED, "mesh BVH needs " + std::to_string(pstack_need) + " packet stack entries (limit " + std::to_string(RT_PSTACK) + ")");
+    if (m.n_prims > RT_PACKET_MAX_PRIMS)
+        return fail(c, RT_ERR_UNSUPPORTED, "mesh BVH with more than " + std::to_string(RT_PACKET_MAX_PRIMS) + " leaf entries");
+    if (std::getenv("RTGPU_DEBUG_BVH")) std::fprintf(stderr, "binary depth %u, wide nodes %u, packet stack %u\n", max_depth, n_inner, pstack_need);
     std::vector<DTri> tris(m.n_prims);
     for (uint32_t r = 0; r < m.n_prims; r++) {
         const uint32_t t = m.prim_indices[r];
