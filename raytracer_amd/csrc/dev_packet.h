@@ -258,6 +258,13 @@ DEV bool in_mask(unsigned long long mask) { return __builtin_amdgcn_inverse_ball
 DEV uint32_t lanes_below(unsigned long long mask) {   // set bits of mask below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
+// This lane's number, worked out on the spot: where registers are short the compiler otherwise keeps the (loop
+// invariant) value in scratch memory and fetches it back for every use.
+DEV uint32_t lane_now() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 DEV void wave_lds_sync() {   // LDS accesses of one wave execute in order; this only keeps the compiler from moving them
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -331,8 +338,8 @@ __device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget
     uint32_t steps = 0;
     const DNode* nodes = uni_ptr(Mg.nodes);
     const DTri* tris = uni_ptr(Mg.tris);
-    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
-    uint32_t* q = rt_qpair + w * RT_QCAP;
+    const uint32_t w = uni(threadIdx.x >> 6), l = threadIdx.x & 63u;
+    const uint32_t wq = w * RT_QCAP;
     PRay pr; float limit; unsigned long long alive;
     {
         const double* qr = rt_qray + w * 6 * 64;
@@ -365,7 +372,7 @@ __device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget
     bool finishing = false;   // nothing left to walk: test what is queued, then leave
     if (root & RT_LEAF_BIT) {
         // a mesh of one leaf
-        if (in_mask(alive)) q[lanes_below(alive)] = ((root & ~RT_LEAF_BIT) << 6) | l;
+        if (in_mask(alive)) rt_qpair[wq + lanes_below(alive)] = ((root & ~RT_LEAF_BIT) << 6) | l;
         qn = (uint32_t)__popcll(alive);
         finishing = true;
     } else st.push(root, alive);
@@ -374,7 +381,7 @@ __device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget
 #define RT_CHILD_ENTERED(r_, m_)                                                                    \
     if (m_) {                                                                                       \
         if ((r_) & RT_LEAF_BIT) {                                                                   \
-            if (in_mask(m_)) q[qn + lanes_below(m_)] = (((r_) & ~RT_LEAF_BIT) << 6) | l;            \
+            if (in_mask(m_)) rt_qpair[wq + qn + lanes_below(m_)] = (((r_) & ~RT_LEAF_BIT) << 6) | lane_now(); \
             qn += (uint32_t)__popcll(m_);                                                           \
         } else st.push((r_), (m_));                                                                 \
     }
@@ -416,7 +423,6 @@ __device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget
     if (unresolved) unresolved = alive;   // the walk ran out of budget: the lanes that are still open
 #undef RT_CHILD_ENTERED
 #undef RT_REDO_CONSTANTS
-    if (qn) test_pairs(tris, 0, qn, vc);
 }
 
 // Scene::cast_ray_once for a whole wave (scene.rs:57-82): the object loop is uniform, meshes are walked as a
