@@ -83,6 +83,18 @@ DEV void pray_axis(double o, double m, float B, float& mf, float& cmin, float& c
     cmin = pos ? lo : hi;   // the min plane is the entry plane when the ray runs in +axis direction
     cmax = pos ? hi : lo;
 }
+// The same from the direction itself, without the f64 division: 1/direction as the f32 reciprocal (1 ulp) of the
+// direction rounded to f32, so the slope is off by up to 3 * 2^-24 instead of 2^-24 and the total by 5 * 2^-24
+// (|o| + B) |m|: the slack is 2^-21.
+DEV void pray_axis_d(double o, double d, float B, float& mf, float& cmin, float& cmax) {
+    mf = fminf(fmaxf(__builtin_amdgcn_rcpf((float)d), -1e30f), 1e30f);
+    const double om = o * (double)mf;
+    const float slack = (fabsf((float)o) + B) * fabsf(mf) * 4.8e-7f;   // 2^-21, rounded up
+    const float lo = __double2float_rd(-om) - slack, hi = __double2float_ru(-om) + slack;
+    const bool pos = !(mf < 0.f);
+    cmin = pos ? lo : hi;
+    cmax = pos ? hi : lo;
+}
 DEV PRay pray_new(const Ray& r, float B) {
     PRay p;
     pray_axis(r.o.x, r.m.x, B, p.mx, p.cminx, p.cmaxx);
@@ -341,30 +353,31 @@ __device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget
     const uint32_t w = uni(threadIdx.x >> 6), l = threadIdx.x & 63u;
     const uint32_t wq = w * RT_QCAP;
     PRay pr; float limit; unsigned long long alive;
-    {
-        const double* qr = rt_qray + w * 6 * 64;
-        const unsigned long long b = rt_qbound[w * 64 + l];
-        const Ray ray = ray_new(d3(qr[l], qr[64 + l], qr[128 + l]), d3(qr[192 + l], qr[256 + l], qr[320 + l]));
-        pr = pray_new(ray, asf(uni(__float_as_uint(Mg.coord_max))));
-        // b - 1 = the bits of the bound, or 0 (a bound that cannot be met: the box distance limit 0 is then as good as any)
-        limit = b > 1 ? __double2float_ru(__longlong_as_double((long long)(b - 1ull))) : 0.f;
-        float tn_root;
-        const bool root_hit = b != 0 && node_box(Mg.root_min, Mg.root_max, ray, tn_root) && !(tn_root > limit);
-        alive = __ballot(root_hit);
-    }
-    // The box-test constants are not carried across a batch of triangle tests (which wants every register it can
-    // get): they are worked out again from the parked ray afterwards.
+    // The box-test constants of this lane's parked ray.  They are not carried across a batch of triangle tests (which
+    // wants every register it can get) but worked out again afterwards.
 #define RT_REDO_CONSTANTS()                                                                                              \
     do {                                                                                                                 \
         const double* qr_ = rt_qray + w * 6 * 64;                                                                        \
         const unsigned long long b_ = rt_qbound[w * 64 + l];                                                             \
-        const D3 o_ = d3(qr_[l], qr_[64 + l], qr_[128 + l]), d_ = d3(qr_[192 + l], qr_[256 + l], qr_[320 + l]);          \
         const float B_ = asf(uni(__float_as_uint(Mg.coord_max)));                                                        \
-        pray_axis(o_.x, 1. / d_.x, B_, pr.mx, pr.cminx, pr.cmaxx);                                                       \
-        pray_axis(o_.y, 1. / d_.y, B_, pr.my, pr.cminy, pr.cmaxy);                                                       \
-        pray_axis(o_.z, 1. / d_.z, B_, pr.mz, pr.cminz, pr.cmaxz);                                                       \
+        pray_axis_d(qr_[l], qr_[192 + l], B_, pr.mx, pr.cminx, pr.cmaxx);                                                \
+        pray_axis_d(qr_[64 + l], qr_[256 + l], B_, pr.my, pr.cminy, pr.cmaxy);                                           \
+        pray_axis_d(qr_[128 + l], qr_[320 + l], B_, pr.mz, pr.cminz, pr.cmaxz);                                          \
+        /* b - 1 = the bits of the bound, or 0 (a bound that cannot be met: the box distance limit 0 is as good as any) */ \
         limit = b_ > 1 ? __double2float_ru(__longlong_as_double((long long)(b_ - 1ull))) : 0.f;                          \
     } while (0)
+    RT_REDO_CONSTANTS();
+    {
+        // the root's own box, with the same constants
+        const float* lo = Mg.root_min; const float* hi = Mg.root_max;
+        const float ax = fmaf(lo[0], pr.mx, pr.cminx), bx = fmaf(hi[0], pr.mx, pr.cmaxx);
+        const float ay = fmaf(lo[1], pr.my, pr.cminy), by = fmaf(hi[1], pr.my, pr.cmaxy);
+        const float az = fmaf(lo[2], pr.mz, pr.cminz), bz = fmaf(hi[2], pr.mz, pr.cmaxz);
+        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        const bool root_hit = rt_qbound[w * 64 + l] != 0 && fmaxf(tn, 0.f) <= fminf(tf, limit);
+        alive = __ballot(root_hit);
+    }
     if (!alive) return;
     const uint32_t root = uni(Mg.root_ref);
     uint32_t qn = 0;
