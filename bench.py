@@ -10,7 +10,7 @@ One step = one frame: every rank renders its interleaved 16x16 tiles (rt_render_
 gathered to rank 0 (RCCL) and scattered into the row-major frame (rt_detile).  The scene is resident in HBM before the
 timed region; the frame stays in HBM.  A ray is one Scene::cast_ray_once call of the reference.
 
-The K timed frames are a sequence (the reference's --sequence workload): --frames-in-flight F (default 3) of them are
+The K timed frames are a sequence (the reference's --sequence workload): --frames-in-flight F (default 4) of them are
 in flight per GPU, each complete and delivered in order; F = 1 renders them strictly one after the other.  The line
 also carries the one-frame-at-a-time figure (`ms_per_frame_alone`).
 """
@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--cells", type=int, default=708)
     ap.add_argument("--lights", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--frames-in-flight", type=int, default=3)
+    ap.add_argument("--frames-in-flight", type=int, default=4)
     args = ap.parse_args()
 
     import torch
