@@ -180,8 +180,10 @@ def main():
         cctx.close()
         del os.environ["RTGPU_COUNT_VISITS"]
         visits = {"lane_node_visits": int(cst.nodes_visited), "lane_tri_tests": int(cst.tris_tested),
-                  "wave_node_fetches": int(cst.wave_nodes), "wave_tri_fetches": int(cst.wave_tris),
-                  "bytes_fetched_by_waves": int(cst.wave_nodes) * 128 + int(cst.wave_tris) * 80}
+                  # wave_tri_steps: triangle records fetched per wave by the closest-hit packets, and rounds of 64
+                  # (ray, leaf) pairs tested by the shadow packets (whose lanes fetch their own triangles)
+                  "wave_node_fetches": int(cst.wave_nodes), "wave_tri_steps": int(cst.wave_tris),
+                  "node_bytes_fetched_by_waves": int(cst.wave_nodes) * 128}
 
     if rank == 0:
         frame_rgb = frame.cpu().numpy().reshape(vh, vw, 3)
@@ -237,7 +239,7 @@ def main():
                          "kernels": kernels,
                          "note": "achieved = bytes the reference's exhaustive walk would read for this launch's casts / launch time; "
                                  "the GPU walk prunes by distance and stops shadow casts at the first blocker, so it reads far less "
-                                 "(gpu_visits) and the figure can exceed the HBM peak; the kernel is VALU-bound (profiles/)"},
+                                 "(gpu_visits) and the figure can exceed the HBM peak; the kernel is bound by instruction issue (profiles/)"},
             "gpu_visits_per_frame": visits,
             "parity_vs_cpu_sample": cpu["parity"],
             "setup_s": {"scene_build": t_build, "upload": t_upload}, "device_bytes": int(st.device_bytes),

@@ -174,8 +174,9 @@ typedef struct rt_stats {
      * variants, slower; "trace" / "shadow" / "shade" instrument one phase only);
      * 0 otherwise. */
     uint64_t nodes_visited, tris_tested;
-    /* the same for the wave-coherent packet walks, counted once per wave (a wave visits a node / tests a
-     * triangle when any of its 64 rays needs it) */
+    /* the same for the wave-coherent packet walks, counted once per wave: nodes a wave visited (it visits a node
+     * when any of its 64 rays needs it); triangle steps = triangles a closest-hit packet tested, plus the rounds
+     * of up to 64 (ray, leaf) pairs a shadow packet tested */
     uint64_t wave_nodes, wave_tris;
     uint32_t launches_trace, launches_shadow, launches_shade, _pad;   /* kernel launches of the last frame */
     /* rays whose walk exceeded its budget and was finished piecewise by the long-ray kernels */
