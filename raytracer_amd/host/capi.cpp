@@ -115,6 +115,17 @@ void rth_mesh_rotate_xyz(std::shared_ptr<Mesh>* m, const double* r) { (*m)->rota
 void rth_mesh_rotate_zyx(std::shared_ptr<Mesh>* m, const double* r) { (*m)->rotate_zyx(V(r)); }
 void rth_mesh_recalculate_normals(std::shared_ptr<Mesh>* m) { (*m)->recalculate_normals(); }
 int rth_mesh_generate_sbvh(std::shared_ptr<Mesh>* m) { std::string e; return (*m)->generate_sbvh(e) ? 0 : fail(e); }
+// Mesh::sbvh is a public field of the reference (mesh.rs:118): a caller may install a tree of their own.  The nodes
+// are taken as given (rt_bvh_node layout: a node's first child is the next record); upload validates them.
+int rth_mesh_set_bvh(std::shared_ptr<Mesh>* m, const rt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* prim_indices, uint32_t n_prims, uint32_t depth) {
+    if (!nodes || !prim_indices || n_nodes == 0 || n_prims == 0) return fail("set_bvh: empty tree");
+    auto b = std::make_shared<FlatBvh>();
+    b->nodes.assign(nodes, nodes + n_nodes);
+    b->prim_indices.assign(prim_indices, prim_indices + n_prims);
+    b->depth = depth;
+    (*m)->sbvh = b;
+    return 0;
+}
 uint32_t rth_mesh_n_tris(std::shared_ptr<Mesh>* m) { return (uint32_t)(*m)->tris.size(); }
 uint32_t rth_mesh_n_verts(std::shared_ptr<Mesh>* m) { return (uint32_t)(*m)->verts.size(); }
 uint32_t rth_mesh_n_normals(std::shared_ptr<Mesh>* m) { return (uint32_t)(*m)->normals.size(); }

@@ -160,6 +160,18 @@ class Mesh:
             raise RuntimeError(N.host_error())
         return self
 
+    BVH_NODE = np.dtype([("min", "<f8", 3), ("max", "<f8", 3), ("right_or_first", "<u4"), ("count", "<u4")])
+
+    def set_bvh(self, nodes, prim_indices, depth=0):
+        """Installs a caller-built tree (the reference's `sbvh` field is public, mesh.rs:118).  `nodes`: array of
+        BVH_NODE records in depth-first order (a node's first child is the next record, `right_or_first` its second;
+        leaves have count > 0 and `right_or_first` = their first entry of `prim_indices`)."""
+        nodes = np.ascontiguousarray(nodes, dtype=Mesh.BVH_NODE)
+        prim = np.ascontiguousarray(prim_indices, dtype=np.uint32)
+        if N.host().rth_mesh_set_bvh(self._h, nodes.ctypes.data, len(nodes), prim.ctypes.data, len(prim), int(depth)):
+            raise RuntimeError(N.host_error())
+        return self
+
     n_tris = property(lambda self: N.host().rth_mesh_n_tris(self._h))
     n_verts = property(lambda self: N.host().rth_mesh_n_verts(self._h))
     n_normals = property(lambda self: N.host().rth_mesh_n_normals(self._h))

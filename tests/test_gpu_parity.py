@@ -322,3 +322,88 @@ def test_sdl_script_renders_like_the_oracle(gpu_ctx):
     assert_parity(rgb, ids, o_rgb, o_ids)
     assert ray_counts(st) == ray_counts(o_st)
     assert oc.would_panic == 0
+
+
+def _spine_mesh(levels, seed=9):
+    """A mesh under a hand-built, deliberately lopsided tree: spine node i holds a pair of large triangles (its first
+    child, two leaves, the larger box) and the rest of the spine (its second child).  The four-wide device tree then
+    uses two spine levels per node (two leaves, the next pair, the rest), and a packet that enters every box -- all
+    triangles overlap around one point -- stacks three entries per node on the way down."""
+    rng = np.random.default_rng(seed)
+    n_tris = 2 * levels + 2
+    verts, tris = [], []
+    for t in range(n_tris):
+        size = 3.0 * 0.93 ** (t // 2)                         # the pairs shrink along the spine, so a pair's box is
+        c = np.array([rng.uniform(-0.1, 0.1) * size, 1.0 + rng.uniform(-0.1, 0.1) * size, -0.001 * t])  # larger than the rest's
+        a = (t % 2) * np.pi / 3 + rng.uniform(-0.1, 0.1)
+        for k in range(3):
+            ang = a + 2 * np.pi * k / 3
+            verts.append(c + size * np.array([np.cos(ang), np.sin(ang), 0.0]))
+        tris.append((3 * t, 3 * t + 1, 3 * t + 2))
+    verts = np.array(verts)
+
+    def box(ts):
+        p = verts[np.array([tris[t] for t in ts]).ravel()]
+        return p.min(0), p.max(0)
+
+    nodes = []
+
+    def leaf(t):
+        lo, hi = box([t])
+        nodes.append((lo, hi, t, 1))
+
+    def spine(i):
+        me = len(nodes)
+        rest = list(range(2 * i, n_tris))
+        lo, hi = box(rest)
+        nodes.append(None)
+        if i == levels:                                       # the last pair
+            leaf(2 * i)
+            right = len(nodes)
+            leaf(2 * i + 1)
+        else:
+            pair = len(nodes)
+            nodes.append(None)
+            leaf(2 * i)
+            pr = len(nodes)
+            leaf(2 * i + 1)
+            plo, phi = box([2 * i, 2 * i + 1])
+            nodes[pair] = (plo, phi, pr, 0)
+            right = len(nodes)
+            spine(i + 1)
+        nodes[me] = (lo, hi, right, 0)
+
+    spine(0)
+    arr = np.zeros(len(nodes), dtype=ra.Mesh.BVH_NODE)
+    for k, (lo, hi, rof, cnt) in enumerate(nodes):
+        arr[k] = (lo, hi, rof, cnt)
+    m = ra.Mesh(scenes.sdl_material(ra.Texture.solid((210, 180, 90)), reflectiveness=0.2))
+    m.set_geometry(verts, tris)
+    m.recalculate_normals()
+    m.set_bvh(arr, np.arange(n_tris, dtype=np.uint32), depth=levels + 2)
+    return m
+
+
+def test_lopsided_tree_fills_the_packet_stack(gpu_ctx):
+    """A caller-built tree close to the limit of the wave-uniform stack renders like the oracle; one beyond it is
+    refused at upload instead of overrunning the stack."""
+    def scene_with(mesh):
+        s = ra.Scene()
+        s.set_camera(ra.Camera(vw=96, vh=64, origin=(0.05, 1.1, 7.0), yaw=0.01, pitch=-0.02))
+        s.skybox_solid((20, 30, 50))
+        s.add_light(ra.Point(position=(1.5, 2.5, 6.0), intensity=30., max_distance=1e9))
+        s.add_light(scenes.sdl_sun((-0.2, -0.4, -1.0)))
+        s.add(mesh)
+        s.add(scenes.sdl_plane((0, -2.5, 0)))
+        return s
+
+    s = scene_with(_spine_mesh(38))
+    gpu_ctx.upload(s)
+    rgb, ids, st = gpu_ctx.render(ids=True)
+    o_rgb, o_ids, o_st, _ = oracle.render(s, 0)
+    assert_parity(rgb, ids, o_rgb, o_ids)
+    assert ray_counts(st) == ray_counts(o_st) and st.rays_shadow > 0
+
+    with pytest.raises(N.RtError) as e:
+        gpu_ctx.upload(scene_with(_spine_mesh(56)))
+    assert e.value.code == N.RT_ERR_UNSUPPORTED and "stack" in str(e.value)
