@@ -100,7 +100,12 @@ typedef struct rt_bvh_node {
 /* mesh.rs:91-119.  Index triples are separate for positions, normals and
  * texture coordinates.  tri_uv may be NULL (no texcoords => uv (0,0)). */
 typedef struct rt_mesh {
-    const double*      verts;      uint32_t n_verts;      uint32_t _p0;   /* [n][3] */
+    const double*      verts;      uint32_t n_verts;                       /* [n][3] */
+    /* Sequences (sdl/src/main.rs:70-95 rebuilds and renders the scene once per frame): nonzero = this mesh --
+     * geometry, normals, texture coordinates and tree -- is the one that stood at the same index in the previous
+     * successful rt_scene_upload of the context.  Its device copy is then kept and the arrays here are not read
+     * (the counts still are, and must match).  Zero: uploaded afresh. */
+    uint32_t           unchanged;
     const double*      normals;    uint32_t n_normals;    uint32_t _p1;   /* [n][3] */
     const float*       texcoords;  uint32_t n_texcoords;  uint32_t _p2;   /* [n][2] */
     const uint32_t*    tri_pos;                                            /* [n_tris][3] */

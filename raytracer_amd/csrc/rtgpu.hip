@@ -44,6 +44,10 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     std::vector<void*> scene_allocs;
+    std::vector<void*>* alloc_sink = &scene_allocs;   // where upload() records what it allocates
+    // the meshes of the last upload, each with the device memory it owns: a mesh flagged `unchanged` keeps its copy
+    struct MeshCopy { DMesh dm; std::vector<void*> allocs; size_t bytes = 0; uint32_t n_verts = 0, n_tris = 0, n_nodes = 0, n_prims = 0; };
+    std::vector<MeshCopy> mesh_copies;
     DScene hscene;                 // host copy of the device scene header
     DScene* dscene = nullptr;
     bool have_scene = false;
@@ -85,6 +89,10 @@ namespace {
 
 int fail(rt_ctx* c, int code, const std::string& msg) { c->err = msg; return code; }
 
+void free_mesh_copies(std::vector<rt_ctx::MeshCopy>& v) {
+    for (auto& m : v) for (void* p : m.allocs) (void)hipFree(p);
+    v.clear();
+}
 void free_scene(rt_ctx* c) {
     for (void* p : c->scene_allocs) (void)hipFree(p);
     c->scene_allocs.clear();
@@ -98,7 +106,7 @@ int upload(rt_ctx* c, const T* src, size_t n, const T** out) {
     if (n == 0) return RT_OK;
     void* d = nullptr;
     if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipMalloc failed during scene upload");
-    c->scene_allocs.push_back(d);
+    c->alloc_sink->push_back(d);
     c->scene_bytes += n * sizeof(T);
     HIP_TRY(c, hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice));
     *out = static_cast<const T*>(d);
@@ -621,6 +629,7 @@ void rt_ctx_destroy(rt_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto ss : c->side) if (ss) (void)hipStreamSynchronize(ss);
     free_scene(c);
+    free_mesh_copies(c->mesh_copies);
     for (auto& la : c->levels) if (la.base) (void)hipFree(la.base);
     for (auto& W : c->lw) {
         if (W.hitlist) (void)hipFree(W.hitlist);
@@ -646,8 +655,18 @@ void rt_ctx_destroy(rt_ctx* c) {
 
 const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
+static int scene_upload(rt_ctx* c, const rt_scene_desc* d);
 int rt_scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     if (!c) return RT_ERR_INVALID;
+    const int rc = scene_upload(c, d);
+    if (rc != RT_OK) {   // a failed upload leaves nothing behind, kept meshes included
+        (void)hipSetDevice(c->device);
+        free_scene(c);
+        free_mesh_copies(c->mesh_copies);
+    }
+    return rc;
+}
+static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     if (!d) return fail(c, RT_ERR_INVALID, "scene is NULL");
     auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(c, hipSetDevice(c->device));
@@ -703,9 +722,35 @@ int rt_scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     }
     if ((rc = upload(c, mats.data(), mats.size(), &H.materials)) != RT_OK) return rc;
 
+    // meshes: one flagged `unchanged` keeps the device copy it had at the same index in the last upload
     std::vector<DMesh> meshes(d->n_meshes);
-    for (uint32_t i = 0; i < d->n_meshes; i++)
-        if ((rc = upload_mesh(c, d->meshes[i], meshes[i])) != RT_OK) return rc;
+    {
+        std::vector<rt_ctx::MeshCopy> old;
+        old.swap(c->mesh_copies);
+        c->mesh_copies.resize(d->n_meshes);
+        rc = RT_OK;
+        for (uint32_t i = 0; i < d->n_meshes && rc == RT_OK; i++) {
+            const rt_mesh& m = d->meshes[i];
+            rt_ctx::MeshCopy& mc = c->mesh_copies[i];
+            if (m.unchanged) {
+                if (i >= old.size() || old[i].allocs.empty())
+                    rc = fail(c, RT_ERR_INVALID, "mesh " + std::to_string(i) + " is flagged unchanged, but the last upload holds no mesh at that index");
+                else if (old[i].n_verts != m.n_verts || old[i].n_tris != m.n_tris || old[i].n_nodes != m.n_nodes || old[i].n_prims != m.n_prims)
+                    rc = fail(c, RT_ERR_INVALID, "mesh " + std::to_string(i) + " is flagged unchanged, but its counts differ from the last upload's");
+                else { mc = std::move(old[i]); old[i].allocs.clear(); c->scene_bytes += mc.bytes; }
+            } else {
+                const size_t before = c->scene_bytes;
+                c->alloc_sink = &mc.allocs;
+                rc = upload_mesh(c, m, mc.dm);
+                c->alloc_sink = &c->scene_allocs;
+                mc.bytes = c->scene_bytes - before;
+                mc.n_verts = m.n_verts; mc.n_tris = m.n_tris; mc.n_nodes = m.n_nodes; mc.n_prims = m.n_prims;
+            }
+            meshes[i] = mc.dm;
+        }
+        free_mesh_copies(old);
+        if (rc != RT_OK) return rc;
+    }
     if ((rc = upload(c, meshes.data(), meshes.size(), &H.meshes)) != RT_OK) return rc;
 
     std::vector<DObject> objs(d->n_objects);

@@ -194,6 +194,11 @@ int rth_scene_save(Scene* s, const char* path) { std::string e; return s->save(p
 LoadedDesc* rth_desc_load(const char* path) { std::string e; LoadedDesc* l = load_desc(path, e); if (!l) g_err = e; return l; }
 const rt_scene_desc* rth_desc_get(LoadedDesc* l) { return desc_of(l); }
 void rth_desc_free(LoadedDesc* l) { free_desc(l); }
+// Sequences: marks every mesh of a flattened scene as unchanged since the context's last upload (rt_mesh::unchanged).
+void rth_desc_keep_meshes(const rt_scene_desc* d, int keep) {
+    rt_mesh* m = const_cast<rt_mesh*>(d->meshes);
+    for (uint32_t i = 0; i < d->n_meshes; i++) m[i].unchanged = keep ? 1u : 0u;
+}
 void rth_desc_set_resolution(LoadedDesc* l, int32_t vw, int32_t vh) {
     rt_scene_desc* d = const_cast<rt_scene_desc*>(desc_of(l)); d->camera.vw = vw; d->camera.vh = vh;
 }

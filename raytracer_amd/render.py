@@ -37,10 +37,14 @@ class Context:
         if rc != N.RT_OK:
             raise N.RtError(rc, N.gpu().rt_last_error(self._c).decode(errors="replace"))
 
-    def upload(self, scene):
-        """scene: anything with .flatten() -> rt_scene_desc address (Scene, LoadedScene)"""
+    def upload(self, scene, keep_meshes=False):
+        """scene: anything with .flatten() -> rt_scene_desc address (Scene, LoadedScene).
+        keep_meshes: the caller's promise that every mesh (geometry, normals, texture coordinates, tree) is the one
+        of this context's previous upload, as in a sequence where only the camera, lights, materials or the other
+        objects move: their device copies are kept (rt_mesh::unchanged)."""
         from .scene import desc_info
         p = scene.flatten()
+        N.host().rth_desc_keep_meshes(p, 1 if keep_meshes else 0)
         self._check(N.gpu().rt_scene_upload(self._c, p))
         info = desc_info(p)
         self.vw, self.vh = info["vw"], info["vh"]

@@ -215,6 +215,40 @@ def test_reupload_sequence_and_determinism(gpu_ctx):
     assert not np.array_equal(frames[0], frames[1])
 
 
+def test_sequence_keeps_unchanged_meshes(gpu_ctx):
+    """frames of a sequence whose meshes do not change (rt_mesh::unchanged): camera, light and a sphere move, the
+    meshes' device copies are kept, and every frame still equals the oracle's"""
+    def frame(k):
+        s = scenes.small_mixed_scene(128, 96)
+        cam = ra.Camera(vw=128, vh=96, origin=(0.3 * k, 3.0 + 0.2 * k, 9.0), yaw=0.02 * k, pitch=-0.3)
+        s.set_camera(cam)
+        s.add(ra.Sphere((-2 + k, 1.5, 1.0), 0.6, scenes.sdl_material(ra.Texture.solid((20, 200, 90)), reflectiveness=0.3)))
+        return s
+
+    s0 = frame(0)
+    gpu_ctx.upload(s0)
+    first = gpu_ctx.render()
+    assert np.array_equal(first[0], oracle.render(s0, 0)[0])
+    bytes_full = first[2].device_bytes
+    for k in (1, 2):
+        s = frame(k)
+        gpu_ctx.upload(s, keep_meshes=True)
+        rgb, _, st = gpu_ctx.render()
+        o_rgb, _, o_st, _ = oracle.render(s, 0)
+        assert np.array_equal(rgb, o_rgb) and ray_counts(st) == ray_counts(o_st)
+        assert st.device_bytes >= bytes_full          # the kept meshes are still accounted for
+        assert not np.array_equal(rgb, first[0])
+    # the promise is checked as far as it can be: the counts must match, and there must be a previous mesh
+    other = scenes.spheres_over_terrain_scene(64, 48, cells=12)
+    with pytest.raises(N.RtError) as e:
+        gpu_ctx.upload(other, keep_meshes=True)
+    assert e.value.code == N.RT_ERR_INVALID and "unchanged" in str(e.value)
+    with pytest.raises(N.RtError):
+        gpu_ctx.upload(other, keep_meshes=True)       # nothing is left after the failed upload
+    gpu_ctx.upload(other)
+    assert np.array_equal(gpu_ctx.render()[0], oracle.render(other, 0)[0])
+
+
 def test_scene_render_through_host_api(tmp_path):
     """the C++ Scene::render / render_to mirror (scene.rs:220-265) end to end"""
     s = scenes.loop_scene(160, 120)
