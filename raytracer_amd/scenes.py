@@ -52,6 +52,27 @@ def procedural_cubemap(cell, seed=1):
     return img
 
 
+# where the reference's stitcher puts the faces in the 4 x 3 atlas, in cells: x+, x-, y+, y-, z+, z- (stitcher/src/main.rs:4)
+CUBEMAP_TILE_OFFSETS = ((2, 1), (0, 1), (1, 0), (1, 2), (1, 1), (3, 1))
+
+
+def stitch_cubemap(xpos, xneg, ypos, yneg, zpos, zneg):
+    """Six square faces (h, w, 3 u8 each, all the same size) -> the 4w x 3h atlas Cubemap skyboxes read
+    (stitcher/src/main.rs:56-98).  The cells no face covers stay black (the reference leaves them transparent black;
+    the skybox never reads them)."""
+    faces = [np.asarray(f) for f in (xpos, xneg, ypos, yneg, zpos, zneg)]
+    h, w = faces[0].shape[:2]
+    if h != w:
+        raise ValueError("The width and height must be the same for each tile")                    # main.rs:69-72
+    for f in faces:
+        if f.shape[:2] != (h, w):
+            raise ValueError("Not all images have the same width/height")                         # main.rs:73-82
+    atlas = np.zeros((3 * h, 4 * w, 3), dtype=np.uint8)
+    for f, (ox, oy) in zip(faces, CUBEMAP_TILE_OFFSETS):
+        atlas[oy * h:(oy + 1) * h, ox * w:(ox + 1) * w] = f[..., :3]
+    return atlas
+
+
 def loop_scene(vw=800, vh=600):
     """README.md:253-274 == scenes/loop.sdl at the default 800x600 camera: 16 grey
     spheres on a ring, one default sun, default Normal skybox."""
