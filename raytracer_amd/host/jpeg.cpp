@@ -1,7 +1,8 @@
-// Baseline JPEG reader for the textures and cubemap atlases the reference's scenes name (the reference decodes
-// them with the `image` crate, interpret.rs:687-696,1109-1119, which pulls in jpeg-decoder 0.1.22; neither is
-// vendored).  Sequential DCT, Huffman coding, 8-bit samples, one or three components, sampling factors 1 and 2,
-// restart intervals.  Progressive files are refused.
+// JPEG reader for the textures and cubemap atlases the reference's scenes name (the reference decodes them with
+// the `image` crate, interpret.rs:687-696,1109-1119, which pulls in jpeg-decoder 0.1.22; neither is vendored).
+// Huffman coding, 8-bit samples, one or three components, sampling factors 1 and 2, restart intervals.  Baseline
+// (one interleaved scan) and progressive (spectral selection and successive approximation over any number of
+// scans: the coefficients are gathered first and turned into samples when the file ends).
 //
 // The arithmetic follows the public-domain stb_image decoder that jpeg-decoder's was derived from: the integer
 // inverse DCT with 12-bit constants, linear interpolation of subsampled chroma, BT.601 YCbCr in f32 with +0.5
@@ -69,6 +70,7 @@ struct Component {
     int dc_pred = 0;
     int w2 = 0, h2 = 0;           // padded plane size in samples
     std::vector<uint8_t> plane;
+    std::vector<int16_t> coef;    // progressive: every block's 64 coefficients (natural order), w2/8 blocks per row
 };
 
 class Decoder {
@@ -77,22 +79,30 @@ class Decoder {
 
     void decode(uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgb) {
         if (get8() != 0xFF || get8() != 0xD8) jfail("not a JPEG file");
-        bool have_frame = false;
+        bool have_frame = false, have_scan = false;
         while (true) {
             int m = next_marker();
-            if (m == 0xD9) jfail("no image data");
-            if (m == 0xC0 || m == 0xC1) { read_frame(); have_frame = true; }
-            else if (m == 0xC2) jfail("progressive JPEG is not supported (baseline only)");
+            if (m == 0xD9) { if (!have_scan) jfail("no image data"); break; }
+            if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+                if (have_frame) jfail("more than one frame");
+                progressive_ = m == 0xC2;
+                read_frame(); have_frame = true;
+            }
             else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) jfail("unsupported JPEG coding process");
             else if (m == 0xC4) read_dht();
             else if (m == 0xDB) read_dqt();
             else if (m == 0xDD) { if (get16() != 4) jfail("bad DRI"); restart_ = get16(); }
             else if (m == 0xDA) {
                 if (!have_frame) jfail("scan before frame header");
-                read_scan();
-                break;
+                if (progressive_) read_scan_progressive(); else read_scan();
+                have_scan = true;
+                if (!progressive_) break;
+                // the bit reader stopped at (or before) the next marker
+                bits_ = 0; nbits_ = 0; hit_marker_ = false;
+                if (p_ >= end_) break;   // a file cut off after its last scan still shows what it holds
             } else skip_segment();
         }
+        if (progressive_) finish_progressive();
         w = (uint32_t)width_; h = (uint32_t)height_;
         to_rgb(rgb);
     }
@@ -101,6 +111,8 @@ class Decoder {
     const uint8_t* p_;
     const uint8_t* end_;
     int width_ = 0, height_ = 0, ncomp_ = 0, hmax_ = 1, vmax_ = 1, restart_ = 0;
+    bool progressive_ = false;
+    int spec_start_ = 0, spec_end_ = 0, succ_high_ = 0, succ_low_ = 0, eob_run_ = 0;
     Component comp_[3];
     uint16_t quant_[4][64] = {};
     bool have_quant_[4] = {false, false, false, false};
@@ -336,6 +348,174 @@ class Decoder {
                     todo = restart_;
                 }
             }
+        }
+    }
+
+    // ---- progressive scans (ITU T.81 annex G)
+    int get_bits(int n) {
+        if (n == 0) return 0;
+        if (nbits_ < n) fill();
+        const int v = (int)(bits_ >> (32 - n));
+        bits_ <<= n; nbits_ -= n;
+        return v;
+    }
+    void block_dc(Component& c, int16_t* d) {
+        if (succ_high_ == 0) {   // first pass: the value, scaled down by the bits still to come
+            std::memset(d, 0, 64 * sizeof(int16_t));
+            const int t = decode_symbol(dc_[c.td]);
+            if (t > 15) jfail("bad DC code");
+            c.dc_pred += receive_extend(t);
+            d[0] = (int16_t)(c.dc_pred * (1 << succ_low_));
+        } else if (get_bits(1)) d[0] = (int16_t)(d[0] + (1 << succ_low_));   // refinement: one more bit
+    }
+    void refine(int16_t& v, int bit) {   // one correction bit for a coefficient that is already non-zero
+        if (get_bits(1) && (v & bit) == 0) v = (int16_t)(v > 0 ? v + bit : v - bit);
+    }
+    void block_ac(Component& c, int16_t* d) {
+        const Huffman& ha = ac_[c.ta];
+        if (succ_high_ == 0) {
+            if (eob_run_) { --eob_run_; return; }
+            int k = spec_start_;
+            do {
+                const int rs = decode_symbol(ha), r = rs >> 4, sz = rs & 15;
+                if (sz == 0) {
+                    if (r < 15) {   // end of band for this block and the next eob_run_ ones
+                        eob_run_ = (1 << r) - 1;
+                        if (r) eob_run_ += get_bits(r);
+                        break;
+                    }
+                    k += 16;
+                } else {
+                    k += r;
+                    if (k > 63) jfail("bad AC run");
+                    d[kZigzag[k++]] = (int16_t)(receive_extend(sz) * (1 << succ_low_));
+                }
+            } while (k <= spec_end_);
+            return;
+        }
+        const int bit = 1 << succ_low_;
+        if (eob_run_) {
+            --eob_run_;
+            for (int k = spec_start_; k <= spec_end_; k++) { int16_t& v = d[kZigzag[k]]; if (v != 0) refine(v, bit); }
+            return;
+        }
+        int k = spec_start_;
+        do {
+            const int rs = decode_symbol(ha);
+            int r = rs >> 4, sz = rs & 15, val = 0;
+            if (sz == 0) {
+                if (r < 15) {
+                    eob_run_ = (1 << r) - 1;
+                    if (r) eob_run_ += get_bits(r);
+                    r = 64;   // to the end of the band: only corrections remain
+                }           // r == 15: sixteen zero coefficients are passed over
+            } else {
+                if (sz != 1) jfail("bad refinement code");
+                val = get_bits(1) ? bit : -bit;
+            }
+            while (k <= spec_end_) {
+                int16_t& v = d[kZigzag[k++]];
+                if (v != 0) refine(v, bit);
+                else {
+                    if (r == 0) { v = (int16_t)val; break; }
+                    --r;
+                }
+            }
+        } while (k <= spec_end_);
+    }
+
+    void plane_sizes() {
+        const int mcu_w = 8 * hmax_, mcu_h = 8 * vmax_;
+        const int mcus_x = (width_ + mcu_w - 1) / mcu_w, mcus_y = (height_ + mcu_h - 1) / mcu_h;
+        for (int i = 0; i < ncomp_; i++) {
+            Component& c = comp_[i];
+            c.w2 = mcus_x * c.h * 8; c.h2 = mcus_y * c.v * 8;
+        }
+    }
+    void restart_if_due(int& todo, bool last) {
+        if (--todo > 0 || last) return;
+        if (nbits_ < 24) fill();
+        bits_ = 0; nbits_ = 0; hit_marker_ = false;
+        const int m = next_marker();
+        if (m < 0xD0 || m > 0xD7) jfail("missing restart marker");
+        for (int i = 0; i < ncomp_; i++) comp_[i].dc_pred = 0;
+        eob_run_ = 0;
+        todo = restart_;
+    }
+    void read_scan_progressive() {
+        const int len = get16();
+        const int ns = get8();
+        if (ns < 1 || ns > ncomp_ || len != 6 + 2 * ns) jfail("bad scan header");
+        int order[3];
+        for (int i = 0; i < ns; i++) {
+            const int id = get8(), q = get8();
+            int which = -1;
+            for (int k = 0; k < ncomp_; k++) if (comp_[k].id == id) which = k;
+            if (which < 0) jfail("scan names an unknown component");
+            order[i] = which;
+            comp_[which].td = q >> 4; comp_[which].ta = q & 15;
+            if (comp_[which].td > 3 || comp_[which].ta > 3) jfail("bad Huffman table index");
+        }
+        spec_start_ = get8(); spec_end_ = get8();
+        const int a = get8();
+        succ_high_ = a >> 4; succ_low_ = a & 15;
+        if (spec_start_ > 63 || spec_end_ > 63 || spec_start_ > spec_end_ || succ_high_ > 13 || succ_low_ > 13) jfail("bad progressive scan parameters");
+        const bool dc_scan = spec_start_ == 0;
+        if (dc_scan && spec_end_ != 0) jfail("a scan cannot hold both DC and AC coefficients");
+        if (!dc_scan && ns != 1) jfail("an AC scan holds one component");
+        for (int i = 0; i < ns; i++) {
+            const Component& c = comp_[order[i]];
+            if (dc_scan ? (succ_high_ == 0 && !dc_[c.td].present) : !ac_[c.ta].present) jfail("scan refers to a missing Huffman table");
+        }
+        if (comp_[0].coef.empty()) {
+            plane_sizes();
+            for (int i = 0; i < ncomp_; i++) comp_[i].coef.assign((size_t)comp_[i].w2 * (size_t)comp_[i].h2, 0);
+        }
+        for (int i = 0; i < ncomp_; i++) comp_[i].dc_pred = 0;
+        eob_run_ = 0;
+        bits_ = 0; nbits_ = 0; hit_marker_ = false;
+        int todo = restart_ ? restart_ : 0x7FFFFFFF;
+        if (ns == 1) {
+            // one component: its blocks in raster order, only those that hold image samples
+            Component& c = comp_[order[0]];
+            const int cx = (width_ * c.h + hmax_ - 1) / hmax_, cy = (height_ * c.v + vmax_ - 1) / vmax_;
+            const int bw = (cx + 7) >> 3, bh = (cy + 7) >> 3, row = c.w2 >> 3;
+            for (int j = 0; j < bh; j++)
+                for (int i = 0; i < bw; i++) {
+                    int16_t* d = c.coef.data() + 64 * ((size_t)j * (size_t)row + (size_t)i);
+                    if (dc_scan) block_dc(c, d); else block_ac(c, d);
+                    restart_if_due(todo, j == bh - 1 && i == bw - 1);
+                }
+            return;
+        }
+        const int mcu_w = 8 * hmax_, mcu_h = 8 * vmax_;
+        const int mcus_x = (width_ + mcu_w - 1) / mcu_w, mcus_y = (height_ + mcu_h - 1) / mcu_h;
+        for (int my = 0; my < mcus_y; my++)
+            for (int mx = 0; mx < mcus_x; mx++) {
+                for (int i = 0; i < ns; i++) {
+                    Component& c = comp_[order[i]];
+                    const int row = c.w2 >> 3;
+                    for (int by = 0; by < c.v; by++)
+                        for (int bx = 0; bx < c.h; bx++)
+                            block_dc(c, c.coef.data() + 64 * ((size_t)(my * c.v + by) * (size_t)row + (size_t)(mx * c.h + bx)));
+                }
+                restart_if_due(todo, my == mcus_y - 1 && mx == mcus_x - 1);
+            }
+    }
+    void finish_progressive() {
+        int coef[64];
+        for (int i = 0; i < ncomp_; i++) {
+            Component& c = comp_[i];
+            if (!have_quant_[c.tq]) jfail("component refers to a missing quantisation table");
+            c.plane.assign((size_t)c.w2 * (size_t)c.h2, 0);
+            const int row = c.w2 >> 3, rows = c.h2 >> 3;
+            for (int j = 0; j < rows; j++)
+                for (int b = 0; b < row; b++) {
+                    const int16_t* d = c.coef.data() + 64 * ((size_t)j * (size_t)row + (size_t)b);
+                    for (int k = 0; k < 64; k++) coef[k] = (int)d[k] * (int)quant_[c.tq][k];
+                    idct(coef, c.plane.data() + (size_t)(j * 8) * (size_t)c.w2 + (size_t)(b * 8), c.w2);
+                }
+            c.coef.clear(); c.coef.shrink_to_fit();
         }
     }
 

@@ -11,7 +11,7 @@
 //   * random(a, b) comes from a seeded generator (the reference uses an unseeded thread_rng, interpret.rs:1305);
 //   * perlin()/simplex() are this library's own gradient noise (the reference calls the un-vendored `noise` 0.7
 //     crate, interpret.rs:1341-1361): same range and character, different values;
-//   * images are PNG or baseline JPEG, decoded by this library's own readers (the reference uses the `image` crate).
+//   * images are PNG or JPEG, decoded by this library's own readers (the reference uses the `image` crate).
 #pragma once
 #include <string>
 

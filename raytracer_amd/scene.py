@@ -414,7 +414,7 @@ def write_png(path, rgb):
 
 
 def read_image(path):
-    """PNG or baseline JPEG (told apart by content) -> (h, w, 3) uint8"""
+    """PNG or JPEG (told apart by content) -> (h, w, 3) uint8"""
     w, h = C.c_uint32(), C.c_uint32()
     if N.host().rth_read_image(str(path).encode(), C.byref(w), C.byref(h), None):
         raise RuntimeError(N.host_error())

@@ -1,5 +1,5 @@
 """Stitches six cube faces into the 4 x 3 atlas a Cubemap skybox reads: the counterpart of the reference's
-`stitcher XPOS XNEG YPOS YNEG ZPOS ZNEG -o cubemap.png` (stitcher/src/main.rs).  Faces: PNG or baseline JPEG."""
+`stitcher XPOS XNEG YPOS YNEG ZPOS ZNEG -o cubemap.png` (stitcher/src/main.rs).  Faces: PNG or JPEG."""
 import argparse
 import os
 import sys
