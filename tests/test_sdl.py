@@ -158,8 +158,12 @@ def test_reference_scenes_that_need_only_shipped_assets_load():
     # a stale scene file: the interpreter has required `tris` since; same refusal as the reference's
     with pytest.raises(RuntimeError, match="property tris must be specified"):
         ra.SdlScene(f"{REF}/scenes/icosahedron.sdl", path=True, base_dir=REF)
-    with pytest.raises(RuntimeError, match="progressive"):     # assets/earth.jpg is a progressive JPEG
-        ra.SdlScene('sphere { position: <0, 0, -3>, radius: 1, material: { texture: image("assets/earth.jpg") } }', base_dir=REF)
+    # assets/earth.jpg is a progressive JPEG (the texture scenes/space.sdl puts on its planet)
+    s = ra.SdlScene('sphere { position: <0, 0, -3>, radius: 1, material: { texture: image("assets/earth.jpg") } }', base_dir=REF)
+    assert ra.desc_info(s.flatten())["n_objects"] == 1
+    # scenes/space.sdl itself names a skybox image the checkout does not hold
+    with pytest.raises(RuntimeError, match="space.png"):
+        ra.SdlScene(f"{REF}/scenes/space.sdl", path=True, base_dir=REF)
 
 
 @needs_ref
