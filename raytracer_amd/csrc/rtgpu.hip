@@ -7,13 +7,16 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtgpu.h"
@@ -141,16 +144,47 @@ void camera_rotation(double pitch, double yaw, double rot[3][3]) {
 
 // Re-emits one mesh: DFS-preorder host nodes (rt_bvh_node) -> inner-node array
 // with both children's boxes, triangles in leaf order with precomputed edges.
+// fn(begin, end) over [0, n) on a few host threads (scene upload: re-emitting a million-triangle tree is host work)
+template <typename F>
+void parallel_for(size_t n, F fn) {
+    size_t nt = std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), 16, n / 16384 + 1});
+    if (const char* e = std::getenv("RTGPU_UPLOAD_THREADS")) nt = std::max<size_t>(1, std::strtoul(e, nullptr, 10));
+    if (nt <= 1) { fn((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (size_t t = 0; t < nt; t++) {
+        const size_t a = std::min(n, t * per), b = std::min(n, a + per);
+        if (a < b) th.emplace_back([=]() { fn(a, b); });
+    }
+    for (auto& t : th) t.join();
+}
+
 int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
     std::memset(&out, 0, sizeof(out));
+    const bool dbg = std::getenv("RTGPU_DEBUG_BVH") != nullptr;
+    auto tm0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "  upload_mesh %-12s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tm0).count());
+        tm0 = t;
+    };
     if (m.n_nodes == 0 || !m.nodes) return fail(c, RT_ERR_INVALID, "mesh without BVH nodes (the reference asserts sbvh.is_some(), mesh.rs:350)");
     if (m.n_tris == 0 || !m.tri_pos || !m.tri_nrm || !m.verts) return fail(c, RT_ERR_INVALID, "mesh without triangles");
     if (m.n_prims == 0 || !m.prim_indices) return fail(c, RT_ERR_INVALID, "mesh without leaf primitive list");
     if (m.n_prims >= 0x7FFFFFFFu) return fail(c, RT_ERR_UNSUPPORTED, "mesh too large");
-    for (uint32_t i = 0; i < 3 * m.n_tris; i++) {
-        if (m.tri_pos[i] >= m.n_verts) return fail(c, RT_ERR_INVALID, "mesh: vertex index out of range");
-        if (m.tri_nrm[i] >= m.n_normals) return fail(c, RT_ERR_INVALID, "mesh: normal index out of range");
-        if (m.tri_uv && m.n_texcoords && m.tri_uv[i] >= m.n_texcoords) return fail(c, RT_ERR_INVALID, "mesh: texcoord index out of range");
+    {
+        std::atomic<int> bad{0};   // 1 vertex, 2 normal, 3 texcoord
+        parallel_for((size_t)3 * m.n_tris, [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                if (m.tri_pos[i] >= m.n_verts) { bad = 1; return; }
+                if (m.tri_nrm[i] >= m.n_normals) { bad = 2; return; }
+                if (m.tri_uv && m.n_texcoords && m.tri_uv[i] >= m.n_texcoords) { bad = 3; return; }
+            }
+        });
+        if (bad == 1) return fail(c, RT_ERR_INVALID, "mesh: vertex index out of range");
+        if (bad == 2) return fail(c, RT_ERR_INVALID, "mesh: normal index out of range");
+        if (bad == 3) return fail(c, RT_ERR_INVALID, "mesh: texcoord index out of range");
     }
     // walk the tree iteratively: validate links, number inner nodes, measure depth
     const uint32_t NN = m.n_nodes;
@@ -179,6 +213,7 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
     for (uint32_t i = 0; i < NN; i++) if (seen[i] && m.nodes[i].count == 0) inner_id[i] = n_inner++;
     for (uint32_t i = 0; i < m.n_prims; i++) if (m.prim_indices[i] >= m.n_tris) return fail(c, RT_ERR_INVALID, "mesh BVH: primitive index out of range");
 
+    lap("validate");
     // f32 box of node i, rounded outward from the slab bounds the reference's test uses:
     // centroid -+ size with centroid = (min+max)*0.5 and size = max - centroid (acceleration.rs:76,135)
     auto box_of = [&](uint32_t i, float* bmin, float* bmax) {
@@ -227,21 +262,14 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
                 kids[best] = e + 1; kids[best + 1] = m.nodes[e].right_or_first;
                 nk++;
             }
+            // topology now (sequential: the numbering depends on it); the boxes are filled in afterwards, in parallel.
+            // Until then pad[k] remembers which reference node slot k shows.
             DNode dn;
             std::memset(&dn, 0, sizeof(dn));
             uint32_t child_dev[4] = {0, 0, 0, 0};
             for (int k = 0; k < 4; k++) {
-                if (k >= nk) {
-                    // empty slot: a box no ray enters
-                    dn.minx[k] = dn.miny[k] = dn.minz[k] = INFINITY;
-                    dn.maxx[k] = dn.maxy[k] = dn.maxz[k] = -INFINITY;
-                    dn.ref[k] = RT_NO_CHILD;
-                    continue;
-                }
-                float bmin[3], bmax[3];
-                box_of(kids[k], bmin, bmax);
-                dn.minx[k] = bmin[0]; dn.miny[k] = bmin[1]; dn.minz[k] = bmin[2];
-                dn.maxx[k] = bmax[0]; dn.maxy[k] = bmax[1]; dn.maxz[k] = bmax[2];
+                if (k >= nk) { dn.ref[k] = RT_NO_CHILD; dn.pad[k] = RT_NONE; continue; }
+                dn.pad[k] = kids[k];
                 const rt_bvh_node& kn = m.nodes[kids[k]];
                 if (kn.count != 0) dn.ref[k] = RT_LEAF_BIT | kn.right_or_first;
                 else { child_dev[k] = (uint32_t)nodes.size(); nodes.emplace_back(); dn.ref[k] = child_dev[k]; }
@@ -254,22 +282,44 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
         }
     }
     n_inner = (uint32_t)nodes.size();
+    parallel_for(nodes.size(), [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            DNode& dn = nodes[i];
+            for (int k = 0; k < 4; k++) {
+                if (dn.pad[k] == RT_NONE) {
+                    // empty slot: a box no ray enters
+                    dn.minx[k] = dn.miny[k] = dn.minz[k] = INFINITY;
+                    dn.maxx[k] = dn.maxy[k] = dn.maxz[k] = -INFINITY;
+                } else {
+                    float bmin[3], bmax[3];
+                    box_of(dn.pad[k], bmin, bmax);
+                    dn.minx[k] = bmin[0]; dn.miny[k] = bmin[1]; dn.minz[k] = bmin[2];
+                    dn.maxx[k] = bmax[0]; dn.maxy[k] = bmax[1]; dn.maxz[k] = bmax[2];
+                }
+                dn.pad[k] = 0;
+            }
+        }
+    });
+    lap("collapse");
     if (pstack_need > RT_PSTACK)
         return fail(c, RT_ERR_UNSUPPORTED, "mesh BVH needs " + std::to_string(pstack_need) + " packet stack entries (limit " + std::to_string(RT_PSTACK) + ")");
     if (m.n_prims > RT_PACKET_MAX_PRIMS)
         return fail(c, RT_ERR_UNSUPPORTED, "mesh BVH with more than " + std::to_string(RT_PACKET_MAX_PRIMS) + " leaf entries");
     if (std::getenv("RTGPU_DEBUG_BVH")) std::fprintf(stderr, "binary depth %u, wide nodes %u, packet stack %u\n", max_depth, n_inner, pstack_need);
-    std::vector<DTri> tris(m.n_prims);
-    for (uint32_t r = 0; r < m.n_prims; r++) {
-        const uint32_t t = m.prim_indices[r];
-        const double* v0 = &m.verts[3 * (size_t)m.tri_pos[3 * t]];
-        const double* v1 = &m.verts[3 * (size_t)m.tri_pos[3 * t + 1]];
-        const double* v2 = &m.verts[3 * (size_t)m.tri_pos[3 * t + 2]];
-        DTri& dt = tris[r];
-        for (int k = 0; k < 3; k++) { dt.v0[k] = v0[k]; dt.e1[k] = v1[k] - v0[k]; dt.e2[k] = v2[k] - v0[k]; }   // mesh.rs:26-27
-        dt.orig = t; dt.last = last[r];
-    }
+    std::unique_ptr<DTri[]> tris(new DTri[m.n_prims]);   // not zeroed: every field is written below, by the thread that first touches the page
+    parallel_for(m.n_prims, [&](size_t a, size_t b) {
+        for (size_t r = a; r < b; r++) {
+            const uint32_t t = m.prim_indices[r];
+            const double* v0 = &m.verts[3 * (size_t)m.tri_pos[3 * t]];
+            const double* v1 = &m.verts[3 * (size_t)m.tri_pos[3 * t + 1]];
+            const double* v2 = &m.verts[3 * (size_t)m.tri_pos[3 * t + 2]];
+            DTri& dt = tris[r];
+            for (int k = 0; k < 3; k++) { dt.v0[k] = v0[k]; dt.e1[k] = v1[k] - v0[k]; dt.e2[k] = v2[k] - v0[k]; }   // mesh.rs:26-27
+            dt.orig = t; dt.last = last[r];
+        }
+    });
     if (!last[m.n_prims - 1]) return fail(c, RT_ERR_INVALID, "mesh BVH: leaf list does not end on a leaf boundary");
+    lap("triangles");
     box_of(0, out.root_min, out.root_max);
     // every child box lies inside the root's (boxes are unions of their descendants'), up to the outward rounding
     out.coord_max = 0.f;
@@ -279,11 +329,12 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
     out.n_inner = n_inner; out.n_tris = m.n_tris; out.n_texcoords = m.tri_uv ? m.n_texcoords : 0;
     int rc;
     if ((rc = upload(c, nodes.data(), nodes.size(), &out.nodes)) != RT_OK) return rc;
-    if ((rc = upload(c, tris.data(), tris.size(), &out.tris)) != RT_OK) return rc;
+    if ((rc = upload(c, tris.get(), (size_t)m.n_prims, &out.tris)) != RT_OK) return rc;
     if ((rc = upload(c, m.normals, (size_t)m.n_normals * 3, &out.normals)) != RT_OK) return rc;
     if ((rc = upload(c, m.texcoords, (size_t)m.n_texcoords * 2, &out.texcoords)) != RT_OK) return rc;
     if ((rc = upload(c, m.tri_nrm, (size_t)m.n_tris * 3, &out.tri_nrm)) != RT_OK) return rc;
     if (m.tri_uv && m.n_texcoords) { if ((rc = upload(c, m.tri_uv, (size_t)m.n_tris * 3, &out.tri_uv)) != RT_OK) return rc; }
+    lap("copies");
     return RT_OK;
 }
 
