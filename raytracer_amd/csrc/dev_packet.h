@@ -382,12 +382,10 @@ __device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget
     const uint32_t root = uni(Mg.root_ref);
     uint32_t qn = 0;
     RStack st; st.ref = 0; st.lo = 0; st.hi = 0; st.sp = 0;
-    bool finishing = false;   // nothing left to walk: test what is queued, then leave
     if (root & RT_LEAF_BIT) {
         // a mesh of one leaf
         if (in_mask(alive)) rt_qpair[wq + lanes_below(alive)] = ((root & ~RT_LEAF_BIT) << 6) | l;
         qn = (uint32_t)__popcll(alive);
-        finishing = true;
     } else st.push(root, alive);
 
     // a child some lane entered: a leaf's (lane, leaf) pairs go on the queue, an inner node on the stack
@@ -400,38 +398,38 @@ __device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget
     }
 
     while (true) {
-        // (the one place where triangles are tested, so that the kernel holds that code once)
-        if (qn >= 64 || (finishing && qn)) {
-            const uint32_t cnt = qn < 64 ? qn : 64;
-            qn -= cnt;
-            test_pairs(tris, qn, cnt, vc);
-            alive &= ~__ballot(parked_blocked());
-            if (!alive) break;
-            if (!finishing && qn < 64) RT_REDO_CONSTANTS();
-            continue;
+        // walk until 64 pairs wait or nothing is left to walk
+        while (st.sp > 0 && qn < 64) {
+            const unsigned long long inmask = st.top_mask() & alive;
+            const uint32_t cur = st.top_ref();
+            --st.sp;
+            if (!inmask) continue;   // everybody who wanted this node has been blocked since
+            if (budget && ++steps > budget) { unresolved = 1; st.sp = 0; break; }
+            const UNode n = RT_ANY_LOAD_NODE(nodes, cur);
+            if (in_mask(inmask)) vc.nodes++;
+            vc.wnodes++;
+            float t0, t1, t2, t3, f0, f1, f2, f3;
+            RT_CHILD_PAIR(n, 0, t0, f0, t1, f1);
+            RT_CHILD_PAIR(n, 2, t2, f2, t3, f3);
+            // the loop runs with every lane of the wave enabled, so a compare's lane mask is already the ballot
+            const unsigned long long m0 = box_lanes(t0, f0, limit) & inmask, m1 = box_lanes(t1, f1, limit) & inmask;
+            unsigned long long m2 = box_lanes(t2, f2, limit) & inmask, m3 = box_lanes(t3, f3, limit) & inmask;
+            if (n.ref[2] == RT_NO_CHILD) m2 = 0;
+            if (n.ref[3] == RT_NO_CHILD) m3 = 0;
+            RT_CHILD_ENTERED(n.ref[3], m3)
+            RT_CHILD_ENTERED(n.ref[2], m2)
+            RT_CHILD_ENTERED(n.ref[1], m1)
+            RT_CHILD_ENTERED(n.ref[0], m0)   // pushed last: walked first (the order makes no measurable difference)
         }
-        if (finishing) break;
-        if (st.sp == 0) { finishing = true; continue; }
-        const unsigned long long inmask = st.top_mask() & alive;
-        if (!inmask) { --st.sp; continue; }   // everybody who wanted this node has been blocked since
-        const uint32_t cur = st.top_ref();
-        --st.sp;
-        if (budget && ++steps > budget) { finishing = true; unresolved = 1; continue; }
-        const UNode n = RT_ANY_LOAD_NODE(nodes, cur);
-        if (in_mask(inmask)) vc.nodes++;
-        vc.wnodes++;
-        float t0, t1, t2, t3, f0, f1, f2, f3;
-        RT_CHILD_PAIR(n, 0, t0, f0, t1, f1);
-        RT_CHILD_PAIR(n, 2, t2, f2, t3, f3);
-        // the loop runs with every lane of the wave enabled, so a compare's lane mask is already the ballot
-        const unsigned long long m0 = box_lanes(t0, f0, limit) & inmask, m1 = box_lanes(t1, f1, limit) & inmask;
-        unsigned long long m2 = box_lanes(t2, f2, limit) & inmask, m3 = box_lanes(t3, f3, limit) & inmask;
-        if (n.ref[2] == RT_NO_CHILD) m2 = 0;
-        if (n.ref[3] == RT_NO_CHILD) m3 = 0;
-        RT_CHILD_ENTERED(n.ref[3], m3)
-        RT_CHILD_ENTERED(n.ref[2], m2)
-        RT_CHILD_ENTERED(n.ref[1], m1)
-        RT_CHILD_ENTERED(n.ref[0], m0)   // pushed last: walked first (the order makes no measurable difference)
+        if (qn == 0) break;
+        // one round of triangle tests (the one place where triangles are tested, so that the kernel holds that code
+        // once); the walk goes on afterwards unless more than a round's worth still waits
+        const uint32_t cnt = qn < 64 ? qn : 64;
+        qn -= cnt;
+        test_pairs(tris, qn, cnt, vc);
+        alive &= ~__ballot(parked_blocked());
+        if (!alive) break;
+        if (st.sp > 0 && qn < 64) RT_REDO_CONSTANTS();
     }
     if (unresolved) unresolved = alive;   // the walk ran out of budget: the lanes that are still open
 #undef RT_CHILD_ENTERED
