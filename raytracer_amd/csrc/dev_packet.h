@@ -344,7 +344,9 @@ __device__ void test_pairs(const DTri* tris, uint32_t base, uint32_t cnt, Visits
 }
 
 // The shadow walk of one mesh for the parked rays.  Every lane of the wave must call it.  Lanes found blocked have
-// their bound word cleared.  budget / unresolved as in packet_traverse.
+// their bound word cleared.  budget / unresolved as in packet_traverse; BUDGET = false compiles the step count out
+// (large launches run without a budget).
+template <bool BUDGET>
 __device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget, unsigned long long& unresolved) {
     unresolved = 0;
     uint32_t steps = 0;
@@ -404,7 +406,7 @@ __device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget
             const uint32_t cur = st.top_ref();
             --st.sp;
             if (!inmask) continue;   // everybody who wanted this node has been blocked since
-            if (budget && ++steps > budget) { unresolved = 1; st.sp = 0; break; }
+            if (BUDGET && ++steps > budget) { unresolved = 1; st.sp = 0; break; }
             const UNode n = RT_ANY_LOAD_NODE(nodes, cur);
             if (in_mask(inmask)) vc.nodes++;
             vc.wnodes++;
@@ -478,6 +480,7 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
 // the last walk nothing of the ray is needed any more, so it does not have to survive the walk in registers).
 // With a budget, a wave whose mesh walk runs long gives up: `unresolved` then holds the lanes whose cast is still
 // open, to be cast again piecewise.
+template <bool BUDGET>
 __device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bool limited, double dist, Visits& vc,
                                 uint32_t budget, unsigned long long& unresolved) {
     const uint32_t n = S.n_linear;
@@ -505,7 +508,7 @@ __device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bo
         const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload);
         if (kind != 3) continue;
         unsigned long long unres = 0;
-        packet_any_deferred(S.meshes[payload], vc, budget, unres);
+        packet_any_deferred<BUDGET>(S.meshes[payload], vc, budget, unres);
         const unsigned long long still = __ballot(open && !parked_blocked());
         // every lane that is not blocked yet is cast again: the meshes after this one were not tried for any of them
         if (unres) { unresolved = still; break; }

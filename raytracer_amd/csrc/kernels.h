@@ -260,7 +260,7 @@ DEV Ray shadow_ray(const RT_GLOBAL DLight* Lt, const double* hs, uint32_t stride
 #ifndef RT_SHADOW_ATTR
 #define RT_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
-template <bool COUNT>
+template <bool COUNT, bool BUDGET>
 __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
                                                                                                           DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
     const uint32_t h = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -276,9 +276,9 @@ __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene
         if (!have) cast = 0;
         // the wave's shadow rays leave neighbouring hit points towards one light: walked as a packet
         unsigned long long unresolved = 0;
-        const bool blocked = cast_any_packet(S, ray, cast != 0, limited, dist, vc, lp.budget_wave, unresolved);
+        const bool blocked = cast_any_packet<BUDGET>(S, ray, cast != 0, limited, dist, vc, lp.budget_wave, unresolved);
         if (cast) occ[(size_t)li * stride + hitlist[hh]] = blocked ? 1 : 0;
-        if (unresolved) {
+        if (BUDGET && unresolved) {
             // the wave gave up: its open rays go on the long-ray list (k_long_shadow sets their byte when blocked)
             const uint32_t cnt = (uint32_t)__popcll(unresolved);
             unsigned long long base = 0;

@@ -555,8 +555,12 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
         if (c->n_lights) {
             // sized for the worst case (every ray hit); threads past the hit count leave at once
             const dim3 sgrid((n + RT_BLOCK - 1) / RT_BLOCK, c->n_lights);
-            if (c->count_visits & 2) hipLaunchKernelGGL(k_shadow<true>, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc, long_shadow, lp);
-            else hipLaunchKernelGGL(k_shadow<false>, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc, long_shadow, lp);
+            {
+                auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc, long_shadow, lp); };
+                const bool cnt = (c->count_visits & 2) != 0;
+                if (lp.budget_wave) { if (cnt) launch(k_shadow<true, true>); else launch(k_shadow<false, true>); }
+                else { if (cnt) launch(k_shadow<true, false>); else launch(k_shadow<false, false>); }
+            }
             if (lp.budget_wave) {
                 if (c->count_visits & 2) hipLaunchKernelGGL(k_long_shadow<true>, dim3(RT_LONG_BLOCKS), block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc, long_shadow);
                 else hipLaunchKernelGGL(k_long_shadow<false>, dim3(RT_LONG_BLOCKS), block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc, long_shadow);
