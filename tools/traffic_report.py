@@ -27,9 +27,12 @@ for k, v in agg.items():
         "fetch_bytes_raw_per_launch": v["FETCH_SIZE"] * 1024 / n, "write_bytes_per_launch": v["WRITE_SIZE"] * 1024 / n,
         "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / n,
     }
-dom = max((k for k in kernels if k.startswith("k_shadow")), key=lambda k: kernels[k]["launches"], default=None)
+# k_shadow comes in variants (with and without a walk budget); a frame's launches are counted together
+sh = [v for k, v in agg.items() if k.startswith("k_shadow")]
+sh_launches = sum(v["launches"] for v in sh)
+sh_bytes = sum((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 for v in sh)
 out = {"kernel": "k_shadow", "n_gpus": 1, "workload_cells": cells, "frames": frames,
-       "hbm_bytes_per_launch": kernels[dom]["hbm_bytes_per_launch"] if dom else None,
+       "hbm_bytes_per_launch": sh_bytes / sh_launches if sh_launches else None,
        "correction": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024; FETCH_SIZE doubled for gfx950's 64-byte tally of 128-byte requests",
        "kernels": kernels}
 print(json.dumps(out, indent=1))
