@@ -354,41 +354,44 @@ __device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget
     const DTri* tris = uni_ptr(Mg.tris);
     const uint32_t w = uni(threadIdx.x >> 6), l = threadIdx.x & 63u;
     const uint32_t wq = w * RT_QCAP;
-    PRay pr; float limit; unsigned long long alive;
-    // The box-test constants of this lane's parked ray.  They are not carried across a batch of triangle tests (which
-    // wants every register it can get) but worked out again afterwards.
+    // Per-lane constants of the box test, as in PRay but filed by role: c_entry goes with the plane the ray meets
+    // first along the axis, c_exit with the other.  Which plane that is (min or max) depends on the direction's sign
+    // only, and the walk below handles lanes of one sign pattern at a time, so it is settled per walk, not per test.
+    float mx, my, mz, enx, eny, enz, exx, exy, exz, limit;
+    // They are not carried across a round of triangle tests (which wants every register it can get) but worked out
+    // again afterwards.
 #define RT_REDO_CONSTANTS()                                                                                              \
     do {                                                                                                                 \
         const double* qr_ = rt_qray + w * 6 * 64;                                                                        \
         const unsigned long long b_ = rt_qbound[w * 64 + l];                                                             \
         const float B_ = asf(uni(__float_as_uint(Mg.coord_max)));                                                        \
-        pray_axis_d(qr_[l], qr_[192 + l], B_, pr.mx, pr.cminx, pr.cmaxx);                                                \
-        pray_axis_d(qr_[64 + l], qr_[256 + l], B_, pr.my, pr.cminy, pr.cmaxy);                                           \
-        pray_axis_d(qr_[128 + l], qr_[320 + l], B_, pr.mz, pr.cminz, pr.cmaxz);                                          \
+        float lo_, hi_;                                                                                                  \
+        pray_axis_d(qr_[l], qr_[192 + l], B_, mx, lo_, hi_); enx = fminf(lo_, hi_); exx = fmaxf(lo_, hi_);               \
+        pray_axis_d(qr_[64 + l], qr_[256 + l], B_, my, lo_, hi_); eny = fminf(lo_, hi_); exy = fmaxf(lo_, hi_);          \
+        pray_axis_d(qr_[128 + l], qr_[320 + l], B_, mz, lo_, hi_); enz = fminf(lo_, hi_); exz = fmaxf(lo_, hi_);         \
         /* b - 1 = the bits of the bound, or 0 (a bound that cannot be met: the box distance limit 0 is as good as any) */ \
         limit = b_ > 1 ? __double2float_ru(__longlong_as_double((long long)(b_ - 1ull))) : 0.f;                          \
     } while (0)
     RT_REDO_CONSTANTS();
+    unsigned long long remaining;
+    uint32_t my_octant;
     {
         // the root's own box, with the same constants
         const float* lo = Mg.root_min; const float* hi = Mg.root_max;
-        const float ax = fmaf(lo[0], pr.mx, pr.cminx), bx = fmaf(hi[0], pr.mx, pr.cmaxx);
-        const float ay = fmaf(lo[1], pr.my, pr.cminy), by = fmaf(hi[1], pr.my, pr.cmaxy);
-        const float az = fmaf(lo[2], pr.mz, pr.cminz), bz = fmaf(hi[2], pr.mz, pr.cmaxz);
-        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        const bool nx = mx < 0.f, ny = my < 0.f, nz = mz < 0.f;
+        my_octant = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+        const float ax = fmaf(nx ? hi[0] : lo[0], mx, enx), bx = fmaf(nx ? lo[0] : hi[0], mx, exx);
+        const float ay = fmaf(ny ? hi[1] : lo[1], my, eny), by = fmaf(ny ? lo[1] : hi[1], my, exy);
+        const float az = fmaf(nz ? hi[2] : lo[2], mz, enz), bz = fmaf(nz ? lo[2] : hi[2], mz, exz);
+        const float tn = fmaxf(fmaxf(ax, ay), az), tf = fminf(fminf(bx, by), bz);
         const bool root_hit = rt_qbound[w * 64 + l] != 0 && fmaxf(tn, 0.f) <= fminf(tf, limit);
-        alive = __ballot(root_hit);
+        remaining = __ballot(root_hit);
     }
-    if (!alive) return;
+    if (!remaining) return;
     const uint32_t root = uni(Mg.root_ref);
     uint32_t qn = 0;
     RStack st; st.ref = 0; st.lo = 0; st.hi = 0; st.sp = 0;
-    if (root & RT_LEAF_BIT) {
-        // a mesh of one leaf
-        if (in_mask(alive)) rt_qpair[wq + lanes_below(alive)] = ((root & ~RT_LEAF_BIT) << 6) | l;
-        qn = (uint32_t)__popcll(alive);
-    } else st.push(root, alive);
+    unsigned long long alive = 0;
 
     // a child some lane entered: a leaf's (lane, leaf) pairs go on the queue, an inner node on the stack
 #define RT_CHILD_ENTERED(r_, m_)                                                                    \
@@ -398,42 +401,89 @@ __device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget
             qn += (uint32_t)__popcll(m_);                                                           \
         } else st.push((r_), (m_));                                                                 \
     }
+    // children k and k+1: entry distance = the latest of the three entry planes, exit = the earliest exit plane
+#define RT_PAIR_ENTRY_EXIT(k, tn_a, tf_a, tn_b, tf_b)                                                                     \
+    do {                                                                                                                  \
+        const rt_f2 ax_ = __builtin_elementwise_fma(rt_f2{asf(pen_x[k]), asf(pen_x[k + 1])}, rt_f2{mx, mx}, rt_f2{enx, enx}); \
+        const rt_f2 bx_ = __builtin_elementwise_fma(rt_f2{asf(pex_x[k]), asf(pex_x[k + 1])}, rt_f2{mx, mx}, rt_f2{exx, exx}); \
+        const rt_f2 ay_ = __builtin_elementwise_fma(rt_f2{asf(pen_y[k]), asf(pen_y[k + 1])}, rt_f2{my, my}, rt_f2{eny, eny}); \
+        const rt_f2 by_ = __builtin_elementwise_fma(rt_f2{asf(pex_y[k]), asf(pex_y[k + 1])}, rt_f2{my, my}, rt_f2{exy, exy}); \
+        const rt_f2 az_ = __builtin_elementwise_fma(rt_f2{asf(pen_z[k]), asf(pen_z[k + 1])}, rt_f2{mz, mz}, rt_f2{enz, enz}); \
+        const rt_f2 bz_ = __builtin_elementwise_fma(rt_f2{asf(pex_z[k]), asf(pex_z[k + 1])}, rt_f2{mz, mz}, rt_f2{exz, exz}); \
+        (tn_a) = fmaxf(fmaxf(ax_.x, ay_.x), az_.x); (tf_a) = fminf(fminf(bx_.x, by_.x), bz_.x);                            \
+        (tn_b) = fmaxf(fmaxf(ax_.y, ay_.y), az_.y); (tf_b) = fminf(fminf(bx_.y, by_.y), bz_.y);                            \
+    } while (0)
 
-    while (true) {
-        // walk until 64 pairs wait or nothing is left to walk
-        while (st.sp > 0 && qn < 64) {
-            const unsigned long long inmask = st.top_mask() & alive;
-            const uint32_t cur = st.top_ref();
-            --st.sp;
-            if (!inmask) continue;   // everybody who wanted this node has been blocked since
-            if (BUDGET && ++steps > budget) { unresolved = 1; st.sp = 0; break; }
-            const UNode n = RT_ANY_LOAD_NODE(nodes, cur);
-            if (in_mask(inmask)) vc.nodes++;
-            vc.wnodes++;
-            float t0, t1, t2, t3, f0, f1, f2, f3;
-            RT_CHILD_PAIR(n, 0, t0, f0, t1, f1);
-            RT_CHILD_PAIR(n, 2, t2, f2, t3, f3);
-            // the loop runs with every lane of the wave enabled, so a compare's lane mask is already the ballot
-            const unsigned long long m0 = box_lanes(t0, f0, limit) & inmask, m1 = box_lanes(t1, f1, limit) & inmask;
-            unsigned long long m2 = box_lanes(t2, f2, limit) & inmask, m3 = box_lanes(t3, f3, limit) & inmask;
-            if (n.ref[2] == RT_NO_CHILD) m2 = 0;
-            if (n.ref[3] == RT_NO_CHILD) m3 = 0;
-            RT_CHILD_ENTERED(n.ref[3], m3)
-            RT_CHILD_ENTERED(n.ref[2], m2)
-            RT_CHILD_ENTERED(n.ref[1], m1)
-            RT_CHILD_ENTERED(n.ref[0], m0)   // pushed last: walked first (the order makes no measurable difference)
+    if (root & RT_LEAF_BIT) {
+        // a mesh of one leaf: nothing to walk
+        alive = remaining;
+        if (in_mask(alive)) rt_qpair[wq + lanes_below(alive)] = ((root & ~RT_LEAF_BIT) << 6) | l;
+        qn = (uint32_t)__popcll(alive);
+        while (qn) {
+            const uint32_t cnt = qn < 64 ? qn : 64;
+            qn -= cnt;
+            test_pairs(tris, qn, cnt, vc);
         }
-        if (qn == 0) break;
-        // one round of triangle tests (the one place where triangles are tested, so that the kernel holds that code
-        // once); the walk goes on afterwards unless more than a round's worth still waits
-        const uint32_t cnt = qn < 64 ? qn : 64;
-        qn -= cnt;
-        test_pairs(tris, qn, cnt, vc);
-        alive &= ~__ballot(parked_blocked());
-        if (!alive) break;
-        if (st.sp > 0 && qn < 64) RT_REDO_CONSTANTS();
+        return;
     }
-    if (unresolved) unresolved = alive;   // the walk ran out of budget: the lanes that are still open
+
+    // The lanes are walked in groups of one direction octant each (shadow rays towards one light nearly always share
+    // it, so there is one group).  Within a group a node record's planes are fetched as "entry planes" and "exit
+    // planes" -- the octant picks the offsets of the six loads -- and a box costs 3 packed FMAs per two children
+    // plus max3, min3, two clamps and a compare: no sorting of each slab's two distances.
+    bool first = true;
+    while (remaining) {
+        if (!first) RT_REDO_CONSTANTS();
+        first = false;
+        const uint32_t octant = (uint32_t)__builtin_amdgcn_readlane((int)my_octant, __ffsll((long long)remaining) - 1);
+        alive = __ballot(my_octant == octant) & remaining;
+        remaining &= ~alive;
+        // 16-byte words of a node record: min x, y, z = 0, 1, 2; max x, y, z = 3, 4, 5; references = 6
+        const uint32_t i_en_x = (octant & 1u) ? 3u : 0u, i_ex_x = (octant & 1u) ? 0u : 3u;
+        const uint32_t i_en_y = (octant & 2u) ? 4u : 1u, i_ex_y = (octant & 2u) ? 1u : 4u;
+        const uint32_t i_en_z = (octant & 4u) ? 5u : 2u, i_ex_z = (octant & 4u) ? 2u : 5u;
+        qn = 0;   // (pairs left over from a group whose lanes are all blocked)
+        st.sp = 0;
+        st.push(root, alive);
+        while (true) {
+            // walk until 64 pairs wait or nothing is left to walk
+            while (st.sp > 0 && qn < 64) {
+                const unsigned long long inmask = st.top_mask() & alive;
+                const uint32_t cur = st.top_ref();
+                --st.sp;
+                if (!inmask) continue;   // everybody who wanted this node has been blocked since
+                if (BUDGET && ++steps > budget) { unresolved = 1; st.sp = 0; break; }
+                const RT_CONST rt_u4* rec = (const RT_CONST rt_u4*)(nodes + cur);
+                const rt_u4 pen_x = rec[i_en_x], pex_x = rec[i_ex_x], pen_y = rec[i_en_y], pex_y = rec[i_ex_y];
+                const rt_u4 pen_z = rec[i_en_z], pex_z = rec[i_ex_z], ref = rec[6];
+                if (in_mask(inmask)) vc.nodes++;
+                vc.wnodes++;
+                float t0, t1, t2, t3, f0, f1, f2, f3;
+                RT_PAIR_ENTRY_EXIT(0, t0, f0, t1, f1);
+                RT_PAIR_ENTRY_EXIT(2, t2, f2, t3, f3);
+                // the loop runs with every lane of the wave enabled, so a compare's lane mask is already the ballot
+                const unsigned long long m0 = box_lanes(t0, f0, limit) & inmask, m1 = box_lanes(t1, f1, limit) & inmask;
+                unsigned long long m2 = box_lanes(t2, f2, limit) & inmask, m3 = box_lanes(t3, f3, limit) & inmask;
+                if (ref[2] == RT_NO_CHILD) m2 = 0;
+                if (ref[3] == RT_NO_CHILD) m3 = 0;
+                RT_CHILD_ENTERED(ref[3], m3)
+                RT_CHILD_ENTERED(ref[2], m2)
+                RT_CHILD_ENTERED(ref[1], m1)
+                RT_CHILD_ENTERED(ref[0], m0)   // pushed last: walked first (the order makes no measurable difference)
+            }
+            if (qn == 0) break;
+            // one round of triangle tests (the one place where triangles are tested, so that the kernel holds that
+            // code once); the walk goes on afterwards unless more than a round's worth still waits
+            const uint32_t cnt = qn < 64 ? qn : 64;
+            qn -= cnt;
+            test_pairs(tris, qn, cnt, vc);
+            alive &= ~__ballot(parked_blocked());
+            if (!alive) break;
+            if (st.sp > 0 && qn < 64) RT_REDO_CONSTANTS();
+        }
+        if (BUDGET && unresolved) { unresolved = alive | remaining; break; }   // out of budget: the lanes still open
+    }
+#undef RT_PAIR_ENTRY_EXIT
 #undef RT_CHILD_ENTERED
 #undef RT_REDO_CONSTANTS
 }
