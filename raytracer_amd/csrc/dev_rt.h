@@ -492,6 +492,9 @@ __device__ bool mesh_intersect(const DMesh& M, const Ray& ray, Hit& h, Visits& v
 
 // ---------------------------------------------------------------- scene casts
 // object.intersect(ray) for object oi (object/mod.rs:61-64)
+// MESHES = false: the caller knows the object is no mesh, and the mesh walk (registers, an LDS stack) stays out of
+// its kernel.
+template <bool MESHES = true>
 __device__ bool object_intersect(const DScene& S, uint32_t oi, const Ray& ray, Hit& h, Visits& vc) {
     const RT_GLOBAL DObject* op = gptr(S.objects) + oi;
     const uint32_t kind = op->kind, payload = op->payload;
@@ -499,7 +502,7 @@ __device__ bool object_intersect(const DScene& S, uint32_t oi, const Ray& ray, H
         case 0: return sphere_intersect(gptr(S.spheres) + 4 * (size_t)payload, ray, h);
         case 1: return plane_intersect(gptr(S.planes) + 8 * (size_t)payload, ray, h);
         case 2: return box_intersect(ld3(gptr(S.boxes) + 6 * (size_t)payload), ld3(gptr(S.boxes) + 6 * (size_t)payload + 3), ray, h);
-        default: return mesh_intersect(S.meshes[payload], ray, h, vc);
+        default: return MESHES ? mesh_intersect(S.meshes[payload], ray, h, vc) : false;
     }
 }
 

@@ -8,7 +8,9 @@
 #define RT_METER 2.                /* lighting/mod.rs:13 */
 #define RT_NONE 0xFFFFFFFFu
 #define RT_MAX_STACK 64            /* deepest mesh BVH the traversal stack holds */
+#ifndef RT_LDS_STACK
 #define RT_LDS_STACK 16            /* stack entries per lane kept in LDS; deeper ones spill to private memory */
+#endif
 
 struct D3 { double x, y, z; };
 

@@ -256,9 +256,11 @@ DEV Ray shadow_ray(const RT_GLOBAL DLight* Lt, const double* hs, uint32_t stride
 // One thread per (lit hit, light): the light's shadow cast.  Lanes of a wave
 // share the light and walk neighbouring hit points, so their shadow rays are coherent.
 // occ[light * stride + ray] = 1 when shadowed.
-// (held to 64 VGPRs = 8 waves per SIMD: the walk waits on one scalar fetch per step, and waves hide that)
+// (held to 7 waves per SIMD, 72 VGPRs: the walk waits on scalar fetches, and waves hide that; 8 waves would fill a
+// CU's LDS with shadow workgroups alone and keep the other kernels of the frames in flight off it -- measured
+// 3 % slower on the whole frame)
 #ifndef RT_SHADOW_ATTR
-#define RT_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#define RT_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(7, 7)))
 #endif
 template <bool COUNT, bool BUDGET>
 __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
@@ -346,7 +348,11 @@ DEV void light_shading(const DLight& Lt, const Ray& ray, const Hit& hit, bool sh
 // What a hit spawns (scene.rs:129-196): the transmitted ray (child 0) and the reflected ray (child 1), the blend
 // flags and the reflection weight.  Needs the hit only, not the lighting, so the next level can be traced while this
 // level's shadow rays are still in flight.
-template <bool COUNT>
+// MESHREF = false: no mesh of the scene has a refracting material (transparency with ior != 1), so the two helper
+// intersects of the refraction branch (scene.rs:143-147) never meet a mesh -- the usual case, and a much lighter
+// kernel (no LDS, a third of the registers), which matters because it sits on the frame's critical path beside a
+// chip full of shadow waves.
+template <bool COUNT, bool MESHREF>
 __global__ __launch_bounds__(RT_BLOCK) void k_spawn(const DScene* Sp, DLevel L, DLevel N, uint32_t n, uint32_t depth,
                                                     uint32_t next_cap, DCounters* C, DLevelCounts* LC, uint32_t* ids_out) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -389,9 +395,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_spawn(const DScene* Sp, DLevel L, 
                         D3 ref_vec;
                         if (refraction_vec(ray.d, hit.normal, 1., ior, ref_vec)) {           // :140 (the reference unwraps)
                             Hit ref_hit;
-                            if (object_intersect(S, obj, ray_new(hit.vnear - ref_vec, ref_vec), ref_hit, vc)) {              // :143
+                            if (object_intersect<MESHREF>(S, obj, ray_new(hit.vnear - ref_vec, ref_vec), ref_hit, vc)) {              // :143
                                 Hit exit_hit;
-                                if (object_intersect(S, obj, ray_new(ref_hit.vfar + ref_vec, -ref_vec), exit_hit, vc)) {     // :145-146
+                                if (object_intersect<MESHREF>(S, obj, ray_new(ref_hit.vfar + ref_vec, -ref_vec), exit_hit, vc)) {     // :145-146
                                     D3 exit_ref_vec;
                                     if (refraction_vec(ref_vec, -exit_hit.normal, ior, 1., exit_ref_vec)) {              // :148-153
                                         want0 = true; c0o = ref_hit.vfar + exit_ref_vec * RT_EPSILON; c0d = exit_ref_vec;  // :155

@@ -69,6 +69,7 @@ struct rt_ctx {
     hipStream_t side[RT_SIDE_STREAMS] = {nullptr, nullptr, nullptr, nullptr};   // shadow + lighting of level d runs on side[d % N]
     LongParams long_params = {0u, 256u};              // walk budgets (inner nodes per lane / per wave) before a ray goes on the long-ray list; 0 = off
     bool any_need_far = false;                        // some mesh's material needs Hit::far (transparency with ior == 1)
+    bool any_mesh_refracts = false;                   // some mesh has a refracting material (transparency with ior != 1): k_spawn needs the mesh walk
     uint32_t packet_depth = 0;                        // levels 0..packet_depth trace their rays as wave packets
     bool serial = false;                              // RTGPU_SERIAL=1: everything on the main stream (profiling: kernels do not overlap)
     uint32_t long_below = 300000u;                  // ... applied to launches of fewer rays than this
@@ -543,10 +544,15 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
             else hipLaunchKernelGGL(k_long_trace<false>, dim3(RT_LONG_BLOCKS), block, 0, s, c->dscene, c->levels[depth].lv, long_trace, hitlist, hs, n, c->dcounters, lc);
         }
         HIP_TRY(c, hipEventRecord(W.ev[LW_T1], s));
-        if (c->count_visits & 4) hipLaunchKernelGGL(k_spawn<true>, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, depth,
-                                                    (uint32_t)next_cap, c->dcounters, lc, depth == 0 ? d_ids : nullptr);
-        else hipLaunchKernelGGL(k_spawn<false>, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, depth,
-                                (uint32_t)next_cap, c->dcounters, lc, depth == 0 ? d_ids : nullptr);
+        {
+            auto launch = [&](auto kern) {
+                hipLaunchKernelGGL(kern, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, depth,
+                                   (uint32_t)next_cap, c->dcounters, lc, depth == 0 ? d_ids : nullptr);
+            };
+            const bool cnt = (c->count_visits & 4) != 0;
+            if (c->any_mesh_refracts) { if (cnt) launch(k_spawn<true, true>); else launch(k_spawn<false, true>); }
+            else { if (cnt) launch(k_spawn<true, false>); else launch(k_spawn<false, false>); }
+        }
         HIP_TRY(c, hipEventRecord(W.ev[LW_P], s));
         // the shadow casts start after k_spawn, not beside it: the spawn is short but on the frame's critical
         // path, and next to a chip full of shadow waves it would crawl
@@ -809,7 +815,7 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     if ((rc = upload(c, meshes.data(), meshes.size(), &H.meshes)) != RT_OK) return rc;
 
     std::vector<DObject> objs(d->n_objects);
-    bool any_far = false;
+    bool any_far = false, any_refr = false;
     for (uint32_t i = 0; i < d->n_objects; i++) {
         const rt_object& o = d->objects[i];
         if (o.material >= d->n_materials) return fail(c, RT_ERR_INVALID, "object: material index out of range");
@@ -820,6 +826,7 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
         objs[i].kind = o.kind; objs[i].material = o.material; objs[i].payload = o.payload;
         objs[i].need_far = (o.kind == RT_OBJ_MESH && m.transparency > RT_EPSILON && m.ior == 1.) ? 1u : 0u;
         if (objs[i].need_far) any_far = true;
+        if (o.kind == RT_OBJ_MESH && m.transparency > RT_EPSILON && !(m.ior == 1.)) any_refr = true;   // (NaN ior included)
     }
     // object tree over the spheres and boxes when there are enough of them to pay for it (RTGPU_TLAS_MIN, default 8)
     {
@@ -891,6 +898,7 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     HIP_TRY(c, hipMemcpy(c->dscene, &H, sizeof(DScene), hipMemcpyHostToDevice));
     c->vw = H.vw; c->vh = H.vh; c->max_depth = H.max_depth; c->n_lights = H.n_lights;
     c->any_need_far = any_far;
+    c->any_mesh_refracts = any_refr;
     c->have_scene = true;
     c->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;
