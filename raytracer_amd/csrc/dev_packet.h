@@ -37,23 +37,6 @@ DEV UNode load_unode(const DNode* nodes, uint32_t idx) {
     n.minx = p[0]; n.miny = p[1]; n.minz = p[2]; n.maxx = p[3]; n.maxy = p[4]; n.maxz = p[5]; n.ref = p[6];
     return n;
 }
-// The same record through the vector memory path: lanes 0..6 fetch 16 bytes each, and the values are handed to the
-// scalar registers lane by lane.
-DEV rt_u4 lane_u4(const rt_u4& v, int lane) {
-    rt_u4 r;
-    r.x = (uint32_t)__builtin_amdgcn_readlane((int)v.x, lane); r.y = (uint32_t)__builtin_amdgcn_readlane((int)v.y, lane);
-    r.z = (uint32_t)__builtin_amdgcn_readlane((int)v.z, lane); r.w = (uint32_t)__builtin_amdgcn_readlane((int)v.w, lane);
-    return r;
-}
-DEV UNode load_unode_v(const DNode* nodes, uint32_t idx) {
-    const uint32_t l = threadIdx.x & 63u;
-    rt_u4 v = {0u, 0u, 0u, 0u};
-    if (l < 8) v = ((const RT_GLOBAL rt_u4*)(nodes + idx))[l];
-    UNode n;
-    n.minx = lane_u4(v, 0); n.miny = lane_u4(v, 1); n.minz = lane_u4(v, 2);
-    n.maxx = lane_u4(v, 3); n.maxy = lane_u4(v, 4); n.maxz = lane_u4(v, 5); n.ref = lane_u4(v, 6);
-    return n;
-}
 DEV TriData load_utri(const DTri* tris, uint32_t rank) {
     const RT_CONST rt_u4* p = (const RT_CONST rt_u4*)(tris + rank);
     const rt_u4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
@@ -149,27 +132,18 @@ struct PStack {
     }
 };
 
-// MODE: TRAV_CLOSEST (nearest hit with t < bound, per lane) or TRAV_ANY (any hit with t <= bound, per lane).
-// Every lane of the wave must call this; `active` says whether the lane carries a ray.
-// TRAV_ANY returns true in the lanes whose ray is blocked.
-// budget: the wave gives up after that many inner nodes (0 = never) and reports the lanes that were still looking
-// in `unresolved`; their rays are then finished piecewise by other lanes (mesh_traverse_seg).
-template <int MODE>
-__device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, double bound, MeshHit& mh, Visits& vc,
-                                uint32_t budget, unsigned long long& unresolved) {
+// Closest hit of a whole wave's rays in one mesh: nearest hit with t < bound per lane, ties to the lower leaf-order
+// index.  Every lane of the wave must call this; `active` says whether the lane carries a ray.
+__device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, double bound, MeshHit& mh, Visits& vc) {
     mh.n = 0; mh.t0 = bound; mh.t1 = bound; mh.r0 = 0;
-    unresolved = 0;
-    uint32_t steps = 0;
     const DNode* nodes = uni_ptr(Mg.nodes);
     const DTri* tris = uni_ptr(Mg.tris);
     float limit = __double2float_ru(bound);
-    bool found = false;
     const PRay pr = pray_new(ray, asf(uni(__float_as_uint(Mg.coord_max))));
 
     float tn_root;
     const bool root_hit = active && node_box(Mg.root_min, Mg.root_max, ray, tn_root) && !(tn_root > limit);
     unsigned long long curmask = __ballot(root_hit);
-    unsigned long long alive = curmask;             // lanes still looking (TRAV_ANY: not yet blocked)
     if (!curmask) return false;
     uint32_t cur = uni(Mg.root_ref);
     PStack st; st.base = &rt_pstack[(threadIdx.x >> 6) * RT_PSTACK]; st.sp = 0;
@@ -178,55 +152,42 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
         if (cur & RT_LEAF_BIT) {
             // ---- a leaf: every triangle, against the lanes that entered the leaf's box
             uint32_t rank = cur & ~RT_LEAF_BIT;
-            const bool in = lane_in(curmask & alive);
+            const bool in = lane_in(curmask);
             while (true) {
                 const TriData T = load_utri(tris, rank);
                 double t; float u, v;
                 if (in) vc.tris++;
                 vc.wtris++;
-                const bool hit = in && tri_test(T, ray, t, u, v);
-                if (MODE == TRAV_ANY) {
-                    if (hit && t <= bound) found = true;
-                } else if (hit) {
-                    if (t < mh.t0 || (t == mh.t0 && rank < mh.r0)) {
-                        mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v; mh.n = 1;
-                        limit = __double2float_ru(t);
-                    }
+                if (in && tri_test(T, ray, t, u, v) && (t < mh.t0 || (t == mh.t0 && rank < mh.r0))) {
+                    mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v; mh.n = 1;
+                    limit = __double2float_ru(t);
                 }
                 if (T.last) break;
                 ++rank;
             }
-            if (MODE == TRAV_ANY) {
-                alive &= ~__ballot(found);
-                if (!alive) break;
-            }
             cur = RT_POP;
         } else {
             // ---- an inner node: four boxes against every lane that entered the node
-            if (budget && ++steps > budget) { unresolved = alive & ~__ballot(found); break; }
             const UNode n = load_unode(nodes, cur);
-            const bool in = lane_in(curmask & alive);
-            if (in) vc.nodes++;
+            if (lane_in(curmask)) vc.nodes++;
             vc.wnodes++;
             float t0, t1, t2, t3, f0, f1, f2, f3;
             RT_CHILD_PAIR(n, 0, t0, f0, t1, f1);
             RT_CHILD_PAIR(n, 2, t2, f2, t3, f3);
             // the loop runs with every lane of the wave enabled, so a compare's lane mask is already the ballot
-            const unsigned long long inmask = curmask & alive;
+            const unsigned long long inmask = curmask;
             unsigned long long m0 = box_lanes(t0, f0, limit) & inmask, m1 = box_lanes(t1, f1, limit) & inmask;
             unsigned long long m2 = box_lanes(t2, f2, limit) & inmask, m3 = box_lanes(t3, f3, limit) & inmask;
             uint32_t r0 = n.ref[0], r1 = n.ref[1], r2 = n.ref[2], r3 = n.ref[3];
             if (r2 == RT_NO_CHILD) m2 = 0;
             if (r3 == RT_NO_CHILD) m3 = 0;
-            if (MODE != TRAV_ANY) {
-                // visit order: by the entry distance of the first lane in each child (rays of a packet agree mostly)
-                const float INF = asf(0x7F800000u);
-                float k0 = m0 ? first_lane_f(t0, m0) : INF, k1 = m1 ? first_lane_f(t1, m1) : INF;
-                float k2 = m2 ? first_lane_f(t2, m2) : INF, k3 = m3 ? first_lane_f(t3, m3) : INF;
-                RT_UCSWAP(k0, r0, m0, k1, r1, m1); RT_UCSWAP(k2, r2, m2, k3, r3, m3);
-                RT_UCSWAP(k0, r0, m0, k2, r2, m2); RT_UCSWAP(k1, r1, m1, k3, r3, m3);
-                RT_UCSWAP(k1, r1, m1, k2, r2, m2);
-            }
+            // visit order: by the entry distance of the first lane in each child (rays of a packet agree mostly)
+            const float INF = asf(0x7F800000u);
+            float k0 = m0 ? first_lane_f(t0, m0) : INF, k1 = m1 ? first_lane_f(t1, m1) : INF;
+            float k2 = m2 ? first_lane_f(t2, m2) : INF, k3 = m3 ? first_lane_f(t3, m3) : INF;
+            RT_UCSWAP(k0, r0, m0, k1, r1, m1); RT_UCSWAP(k2, r2, m2, k3, r3, m3);
+            RT_UCSWAP(k0, r0, m0, k2, r2, m2); RT_UCSWAP(k1, r1, m1, k3, r3, m3);
+            RT_UCSWAP(k1, r1, m1, k2, r2, m2);
             // children nobody entered have an empty mask; the first non-empty one is next, the rest are stacked
             cur = RT_POP;
             if (m3) { cur = r3; curmask = m3; }
@@ -235,15 +196,11 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
             if (m0) { if (cur != RT_POP) st.push(cur, curmask); cur = r0; curmask = m0; }
         }
         if (cur == RT_POP) {
-            while (st.sp > 0) {
-                uint32_t r; unsigned long long m;
-                st.pop(r, m);
-                if (m & alive) { cur = r; curmask = m; break; }
-            }
-            if (cur == RT_POP) break;
+            if (st.sp == 0) break;
+            st.pop(cur, curmask);
         }
     }
-    return MODE == TRAV_ANY ? found : (mh.n > 0);
+    return mh.n > 0;
 }
 
 // ---- shadow casts with the triangle tests set aside
@@ -256,9 +213,6 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
 // hit clears the owner's bound word; owners look at their word after each batch and leave the packet.
 // What is tested is unchanged (each ray against the triangles of the leaves its box chain reached, until the ray is
 // known to be blocked), only later.
-#ifndef RT_ANY_LOAD_NODE
-#define RT_ANY_LOAD_NODE load_unode
-#endif
 #define RT_QCAP 320                       /* 63 pairs left over + the up to 4 x 64 one node step can add */
 #define RT_PACKET_MAX_PRIMS (1u << 26)    /* a pair is (leaf's first triangle << 6) | lane in one word */
 #define RT_PWAVES (RT_BLOCK_DIM / 64)
@@ -344,8 +298,9 @@ __device__ void test_pairs(const DTri* tris, uint32_t base, uint32_t cnt, Visits
 }
 
 // The shadow walk of one mesh for the parked rays.  Every lane of the wave must call it.  Lanes found blocked have
-// their bound word cleared.  budget / unresolved as in packet_traverse; BUDGET = false compiles the step count out
-// (large launches run without a budget).
+// their bound word cleared.  With BUDGET the wave gives up after `budget` inner nodes and reports the lanes that
+// were still open in `unresolved` (their rays are then finished piecewise by other lanes, mesh_traverse_seg);
+// BUDGET = false compiles the step count out (large launches run without a budget).
 template <bool BUDGET>
 __device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget, unsigned long long& unresolved) {
     unresolved = 0;
@@ -496,7 +451,6 @@ template <bool FAR>
 __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active, Closest& c, Visits& vc) {
     c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
     bool any = false;
-    unsigned long long unres = 0;
     const uint32_t n = S.n_linear;
     const RT_GLOBAL DObject* objs = gptr(S.objects);
     for (uint32_t li_ = 0; li_ < n; li_++) {
@@ -509,7 +463,7 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
                 if (active && mesh_traverse<TRAV_TWO>(S.meshes[payload], ray, INFINITY, mh, vc) && (!any || mh.t0 < c.t)) {
                     c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.n >= 2 ? mh.t1 : mh.t0; c.u = mh.u; c.v = mh.v; any = true;
                 }
-            } else if (packet_traverse<TRAV_CLOSEST>(S.meshes[payload], ray, active, any ? c.t : INFINITY, mh, vc, 0, unres)) {
+            } else if (packet_traverse(S.meshes[payload], ray, active, any ? c.t : INFINITY, mh, vc)) {
                 c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.t0; c.u = mh.u; c.v = mh.v; any = true;
             }
             continue;
