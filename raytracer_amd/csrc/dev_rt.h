@@ -562,6 +562,7 @@ __device__ bool tlas_any(const DScene& S, const Ray& ray, bool limited, double d
 // walk: every object whose box the ray enters before the best distance is tested, ties go to the lower index.
 __device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c, bool any) {
     const RT_GLOBAL DTlasNode* nodes = (const RT_GLOBAL DTlasNode*)S.tlas;
+    const RT_GLOBAL DTlasWide* wide = (const RT_GLOBAL DTlasWide*)S.tlas_wide;
     const bool cull = tlas_culls(ray);
     const float INF = __uint_as_float(0x7F800000u);
     int sp = 0;
@@ -569,33 +570,38 @@ __device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c
     float limit = any ? __double2float_ru(c.t) : INF;
     float tn_root = -INF;
     if (cull && !(node_box(nodes[0].bmin, nodes[0].bmax, ray, tn_root) && !(tn_root > limit))) return any;
+    // an object reached through a leaf reference: nearest by `near`, ties to the lower index
+    auto object = [&](uint32_t oi) {
+        double near;
+        if (tlas_object_near(S, oi, ray, near) && (!any || near < c.t || (near == c.t && oi < c.obj))) {
+            c.obj = oi; c.rank = RT_NONE; c.t = near; c.t2 = 0.; c.u = 0.f; c.v = 0.f; any = true;
+            limit = __double2float_ru(near);
+        }
+    };
     uint32_t cur = 0;
     while (true) {
-        const uint32_t info = nodes[cur].object;
-        if (!(info & RT_TLAS_INNER)) {
-            double near;
-            if (tlas_object_near(S, info, ray, near) && (!any || near < c.t || (near == c.t && info < c.obj))) {
-                c.obj = info; c.rank = RT_NONE; c.t = near; c.t2 = 0.; c.u = 0.f; c.v = 0.f; any = true;
-                limit = __double2float_ru(near);
-            }
-            cur = RT_POP;
-        } else {
-            const uint32_t l = cur + 1, r = info & ~RT_TLAS_INNER;
-            float tl = -INF, tr = -INF;
-            bool hl = true, hr = true;
-            if (cull) {
-                hl = node_box(nodes[l].bmin, nodes[l].bmax, ray, tl) && !(tl > limit);
-                hr = node_box(nodes[r].bmin, nodes[r].bmax, ray, tr) && !(tr > limit);
-            }
-            if (hl && hr) {
-                const bool left_first = !(tr < tl);
-                const uint32_t far = left_first ? r : l;
-                const float tfar = left_first ? tr : tl;
-                if (sp >= RT_MAX_STACK) return any;   // cannot happen: a median-split tree over < 2^31 objects is < 32 deep
-                RT_STACK_PUSH(far, tfar);
-                cur = left_first ? l : r;
-            } else cur = hl ? l : hr ? r : RT_POP;
+        // one record: both children's boxes (four 16-byte loads)
+        const RT_GLOBAL rt_d2* p = (const RT_GLOBAL rt_d2*)(wide + cur);
+        union { rt_d2 q[4]; DTlasWide w; } rec;
+        rec.q[0] = p[0]; rec.q[1] = p[1]; rec.q[2] = p[2]; rec.q[3] = p[3];
+        const DTlasWide& W = rec.w;
+        float tl = -INF, tr = -INF;
+        bool hl = true, hr = true;
+        if (cull) {
+            hl = node_box(W.lmin, W.lmax, ray, tl) && !(tl > limit);
+            hr = node_box(W.rmin, W.rmax, ray, tr) && !(tr > limit);
         }
+        // leaves are tested on the spot; what they find may close the other child
+        if (hl && (W.left & RT_TLAS_LEAF)) { object(W.left & ~RT_TLAS_LEAF); hl = false; }
+        if (hr && (W.right & RT_TLAS_LEAF)) { if (!(tr > limit)) object(W.right & ~RT_TLAS_LEAF); hr = false; }
+        if (hl && tl > limit) hl = false;
+        if (hr && tr > limit) hr = false;
+        if (hl && hr) {
+            const bool left_first = !(tr < tl);
+            if (sp >= RT_MAX_STACK) return any;   // cannot happen: a median-split tree over < 2^31 objects is < 32 deep
+            RT_STACK_PUSH(left_first ? W.right : W.left, left_first ? tr : tl);
+            cur = left_first ? W.left : W.right;
+        } else cur = hl ? W.left : hr ? W.right : RT_POP;
         if (cur == RT_POP) {
             while (sp > 0) {
                 uint2 e;

@@ -69,6 +69,16 @@ struct DTlasNode {
 };
 #define RT_TLAS_INNER 0x80000000u
 
+// The same tree for the walks that own a stack (the lane-by-lane trace kernels): one 64-byte record per inner node
+// with the boxes of BOTH children, so a level of the tree costs one dependent fetch instead of two, and leaves need no
+// record at all (a child reference is RT_TLAS_LEAF | object index, or the index of the child's own record).
+struct __attribute__((aligned(16))) DTlasWide {
+    float lmin[3], lmax[3], rmin[3], rmax[3];
+    uint32_t left, right;
+    uint32_t pad[2];
+};
+#define RT_TLAS_LEAF 0x80000000u
+
 struct DMaterial {
     uint32_t tex_kind;
     uint32_t tex_w, tex_h;
@@ -103,6 +113,7 @@ struct DScene {
     const double* boxes;            // [n][6] pos, half
     const DMesh* meshes;
     const DTlasNode* tlas;          // null when the scene has few analytic objects
+    const DTlasWide* tlas_wide;     // the inner nodes of the same tree, two child boxes each (record 0 = the root)
     const uint32_t* linear;         // indices of the objects the casts scan one by one (all that are not in the tree)
     uint32_t n_tlas, n_linear;
     const DMaterial* materials;

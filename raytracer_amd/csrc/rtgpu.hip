@@ -525,13 +525,14 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
         hipStream_t side = c->serial ? s : c->side[depth % RT_SIDE_STREAMS];
         const dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
         HIP_TRY(c, hipEventRecord(W.ev[LW_T0], s));
-        // depth 0: primary rays, 8x8 pixel blocks per wave -> coherent packets; deeper rays are walked lane by lane
+        // depth 0 of a scene with meshes: primary rays, 8x8 pixel blocks per wave -> coherent packets; deeper rays
+        // (and scenes of analytic objects only, whose object tree is walked per lane anyway) lane by lane
         {
             auto launch = [&](auto kern) {
                 hipLaunchKernelGGL(kern, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters, lc, long_trace, lp);
             };
             const bool cnt = (c->count_visits & 1) != 0;
-            if (depth <= c->packet_depth) {
+            if (depth <= c->packet_depth && c->hscene.n_meshes > 0) {   // packets pay for mesh walks only
                 if (c->any_need_far) { if (cnt) launch(k_trace<true, true, false, true>); else launch(k_trace<false, true, false, true>); }
                 else { if (cnt) launch(k_trace<true, true, false, false>); else launch(k_trace<false, true, false, false>); }
             }
@@ -847,7 +848,7 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
         }
         uint32_t tlas_min = 8;
         if (const char* e = std::getenv("RTGPU_TLAS_MIN")) tlas_min = (uint32_t)std::strtoul(e, nullptr, 10);
-        H.tlas = nullptr; H.n_tlas = 0;
+        H.tlas = nullptr; H.tlas_wide = nullptr; H.n_tlas = 0;
         if (items.size() >= std::max<uint32_t>(tlas_min, 2)) {
             std::vector<DTlasNode> nodes;
             nodes.reserve(items.size() * 2);
@@ -855,6 +856,24 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
             for (const TlasItem& it : items) objs[it.object].need_far |= RT_IN_TLAS;
             if ((rc = upload(c, nodes.data(), nodes.size(), &H.tlas)) != RT_OK) return rc;
             H.n_tlas = (uint32_t)nodes.size();
+            // the wide records: inner nodes in the order they appear (so the root is record 0)
+            std::vector<uint32_t> wide_of(nodes.size(), 0);
+            uint32_t n_wide = 0;
+            for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].object & RT_TLAS_INNER) wide_of[i] = n_wide++;
+            std::vector<DTlasWide> wide(n_wide);
+            for (size_t i = 0; i < nodes.size(); i++) {
+                if (!(nodes[i].object & RT_TLAS_INNER)) continue;
+                DTlasWide& w = wide[wide_of[i]];
+                std::memset(&w, 0, sizeof(w));
+                const size_t l = i + 1, r = nodes[i].object & ~RT_TLAS_INNER;
+                for (int k = 0; k < 3; k++) {
+                    w.lmin[k] = nodes[l].bmin[k]; w.lmax[k] = nodes[l].bmax[k];
+                    w.rmin[k] = nodes[r].bmin[k]; w.rmax[k] = nodes[r].bmax[k];
+                }
+                w.left = (nodes[l].object & RT_TLAS_INNER) ? wide_of[l] : (RT_TLAS_LEAF | nodes[l].object);
+                w.right = (nodes[r].object & RT_TLAS_INNER) ? wide_of[r] : (RT_TLAS_LEAF | nodes[r].object);
+            }
+            if ((rc = upload(c, wide.data(), wide.size(), &H.tlas_wide)) != RT_OK) return rc;
         }
     }
     if ((rc = upload(c, objs.data(), objs.size(), &H.objects)) != RT_OK) return rc;
