@@ -718,27 +718,71 @@ __device__ bool cast_any_seg(const DScene& S, const Ray& ray, bool limited, doub
     return S.n_tlas != 0 && tlas_any(S, ray, limited, dist);
 }
 
-// Shadow casts.  sun.rs:89: any object the ray hits at all; point.rs:91-92:
-// the nearest hit has near <= dist, i.e. some object has near <= dist.
-__device__ bool cast_any(const DScene& S, const Ray& ray, bool limited, double dist, Visits& vc) {
+// tlas_any for a kernel that owns a per-lane stack: the wide records, nearer child first (a blocker near the ray's
+// start ends the walk early), nothing beyond `dist` entered.
+__device__ bool tlas_any_ordered(const DScene& S, const Ray& ray, bool limited, double dist) {
+    const RT_GLOBAL DTlasNode* nodes = (const RT_GLOBAL DTlasNode*)S.tlas;
+    const RT_GLOBAL DTlasWide* wide = (const RT_GLOBAL DTlasWide*)S.tlas_wide;
+    const bool cull = tlas_culls(ray);
+    const float INF = __uint_as_float(0x7F800000u);
+    int sp = 0;
+    volatile unsigned long long spill[RT_MAX_STACK - RT_LDS_STACK];
+    const float limit = limited ? __double2float_ru(dist) : INF;
+    float tn_root = -INF;
+    if (cull && !(node_box(nodes[0].bmin, nodes[0].bmax, ray, tn_root) && !(tn_root > limit))) return false;
+    uint32_t cur = 0;
+    while (true) {
+        const RT_GLOBAL rt_d2* p = (const RT_GLOBAL rt_d2*)(wide + cur);
+        union { rt_d2 q[4]; DTlasWide w; } rec;
+        rec.q[0] = p[0]; rec.q[1] = p[1]; rec.q[2] = p[2]; rec.q[3] = p[3];
+        const DTlasWide& W = rec.w;
+        float tl = -INF, tr = -INF;
+        bool hl = true, hr = true;
+        if (cull) {
+            hl = node_box(W.lmin, W.lmax, ray, tl) && !(tl > limit);
+            hr = node_box(W.rmin, W.rmax, ray, tr) && !(tr > limit);
+        }
+        double near;
+        if (hl && (W.left & RT_TLAS_LEAF)) {
+            if (tlas_object_near(S, W.left & ~RT_TLAS_LEAF, ray, near) && (!limited || near <= dist)) return true;
+            hl = false;
+        }
+        if (hr && (W.right & RT_TLAS_LEAF)) {
+            if (tlas_object_near(S, W.right & ~RT_TLAS_LEAF, ray, near) && (!limited || near <= dist)) return true;
+            hr = false;
+        }
+        if (hl && hr) {
+            const bool left_first = !(tr < tl);
+            if (sp >= RT_MAX_STACK) return false;   // cannot happen: a median-split tree over < 2^31 objects is < 32 deep
+            RT_STACK_PUSH(left_first ? W.right : W.left, 0.f);
+            cur = left_first ? W.left : W.right;
+        } else cur = hl ? W.left : hr ? W.right : RT_POP;
+        if (cur == RT_POP) {
+            if (sp == 0) break;
+            uint2 e;
+            RT_STACK_POP(e);
+            cur = e.x;
+        }
+    }
+    return false;
+}
+
+// Shadow cast of one lane in a scene without meshes (sun.rs:89: any object the ray hits at all; point.rs:91-92: the
+// nearest hit has near <= dist, i.e. some object has near <= dist).
+__device__ bool cast_any_analytic(const DScene& S, const Ray& ray, bool limited, double dist) {
     const uint32_t n = S.n_linear;
     const RT_GLOBAL DObject* objs = gptr(S.objects);
     for (uint32_t li_ = 0; li_ < n; li_++) {
         const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
-        struct { uint32_t kind, payload; } o;
-        o.kind = objs[oi].kind; o.payload = objs[oi].payload;
+        const uint32_t kind = objs[oi].kind, payload = objs[oi].payload;
         double near; bool hit;
-        if (o.kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)o.payload, ray, near);
-        else if (o.kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)o.payload, ray, near);
-        else if (o.kind == 2) hit = box_near(gptr(S.boxes) + 6 * (size_t)o.payload, ray, near);
-        else {
-            MeshHit mh;
-            if (mesh_traverse<TRAV_ANY>(S.meshes[o.payload], ray, limited ? dist : INFINITY, mh, vc)) return true;
-            continue;
-        }
+        if (kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
+        else if (kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)payload, ray, near);
+        else if (kind == 2) hit = box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
+        else continue;
         if (hit && (!limited || near <= dist)) return true;
     }
-    return S.n_tlas != 0 && tlas_any(S, ray, limited, dist);
+    return S.n_tlas != 0 && tlas_any_ordered(S, ray, limited, dist);
 }
 
 // Rebuilds the full Hit of the closest object from the trace record

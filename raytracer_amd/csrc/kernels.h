@@ -300,6 +300,23 @@ __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene
     } else block_count3(cast, 0, 0, &sh->rays_shadow, nullptr, nullptr);
 }
 
+// k_shadow for a scene without meshes: nothing to walk as a packet, so every lane casts on its own, through the
+// object tree's wide records with a stack of its own.
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow_lanes(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
+                                                           DCounters* C, const DLevelCounts* LC) {
+    const uint32_t h = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t li = blockIdx.y;
+    const DScene& S = *Sp;
+    uint32_t cast = 0;
+    if (h < (uint32_t)LC->hit_count) {
+        bool limited; double dist;
+        const Ray ray = shadow_ray(gptr(S.lights) + li, hs, stride, h, cast, limited, dist);
+        if (cast) occ[(size_t)li * stride + hitlist[h]] = cast_any_analytic(S, ray, limited, dist) ? 1 : 0;
+    }
+    block_count3(cast, 0, 0, &my_shard(C)->rays_shadow, nullptr, nullptr);
+}
+
 // The listed long shadow rays, RT_SEGS lanes each: any piece that finds a blocker sets the ray's byte.
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_long_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,

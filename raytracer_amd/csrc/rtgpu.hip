@@ -562,7 +562,10 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
         if (c->n_lights) {
             // sized for the worst case (every ray hit); threads past the hit count leave at once
             const dim3 sgrid((n + RT_BLOCK - 1) / RT_BLOCK, c->n_lights);
-            {
+            if (c->hscene.n_meshes == 0) {
+                lp.budget_wave = 0;   // (no long-ray pass: nothing is walked as a packet)
+                hipLaunchKernelGGL(k_shadow_lanes<false>, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc);
+            } else {
                 auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc, long_shadow, lp); };
                 const bool cnt = (c->count_visits & 2) != 0;
                 if (lp.budget_wave) { if (cnt) launch(k_shadow<true, true>); else launch(k_shadow<false, true>); }
