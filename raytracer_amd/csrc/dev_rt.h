@@ -651,6 +651,26 @@ __device__ bool cast_closest(const DScene& S, const Ray& ray, Closest& c, Visits
     return any;
 }
 
+// cast_closest in a scene without meshes
+__device__ bool cast_closest_analytic(const DScene& S, const Ray& ray, Closest& c) {
+    c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
+    bool any = false;
+    const uint32_t n = S.n_linear;
+    const RT_GLOBAL DObject* objs = gptr(S.objects);
+    for (uint32_t li_ = 0; li_ < n; li_++) {
+        const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
+        const uint32_t kind = objs[oi].kind, payload = objs[oi].payload;
+        double near; bool hit;
+        if (kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
+        else if (kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)payload, ray, near);
+        else if (kind == 2) hit = box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
+        else continue;
+        if (hit && (!any || near < c.t)) { c.obj = oi; c.rank = RT_NONE; c.t = near; any = true; }
+    }
+    if (S.n_tlas) any = tlas_closest_ordered(S, ray, c, any);
+    return any;
+}
+
 // cast_closest with every plain mesh walk restricted to `sg_of(mesh)`: `k`/`K` pick the piece (K = 1: the whole
 // ray), `budget` bounds each walk.  aborted = some walk gave up; the result is then incomplete.
 __device__ bool cast_closest_seg(const DScene& S, const Ray& ray, Closest& c, Visits& vc, uint32_t k, uint32_t K, uint32_t budget, bool& aborted) {
@@ -786,10 +806,11 @@ __device__ bool cast_any_analytic(const DScene& S, const Ray& ray, bool limited,
 }
 
 // Rebuilds the full Hit of the closest object from the trace record
+template <bool MESHES = true>
 __device__ void closest_hit_fill(const DScene& S, const Ray& ray, uint32_t obj, uint32_t rank, double t, double t2, float u, float v, Hit& h) {
     const RT_GLOBAL DObject* op = gptr(S.objects) + obj;
     const uint32_t kind = op->kind, payload = op->payload;
-    if (kind == 3) mesh_hit_fill(S.meshes[payload], ray, rank, t, t2, u, v, h);
+    if (MESHES && kind == 3) mesh_hit_fill(S.meshes[payload], ray, rank, t, t2, u, v, h);
     else if (kind == 0) sphere_intersect(gptr(S.spheres) + 4 * (size_t)payload, ray, h);
     else if (kind == 1) plane_intersect(gptr(S.planes) + 8 * (size_t)payload, ray, h);
     else box_intersect(ld3(gptr(S.boxes) + 6 * (size_t)payload), ld3(gptr(S.boxes) + 6 * (size_t)payload + 3), ray, h);

@@ -9,7 +9,7 @@
 #define RT_NONE 0xFFFFFFFFu
 #define RT_MAX_STACK 64            /* deepest mesh BVH the traversal stack holds */
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 16            /* stack entries per lane kept in LDS; deeper ones spill to private memory */
+#define RT_LDS_STACK 8             /* stack entries per lane kept in LDS (16 KB per workgroup, so that LDS does not cap the waves per SIMD); deeper ones spill to private memory */
 #endif
 
 struct D3 { double x, y, z; };

@@ -131,6 +131,7 @@ struct LongParams { uint32_t budget_lane, budget_wave; };
 
 // what k_trace does with the closest hit of ray i: the hit record, and the entry of the shadow work list
 // (hit point and the offset origin vnear + normal * EPSILON of sun.rs:88, point.rs:90) when the hit will be lit
+template <bool MESHES = true>
 DEV void trace_finish(const DScene& S, DLevel& L, uint32_t i, bool active, const Ray& ray, bool hit, const Closest& c,
                       uint32_t* hitlist, double* hs, uint32_t stride, DLevelCounts* LC) {
     bool lit = false;
@@ -143,7 +144,7 @@ DEV void trace_finish(const DScene& S, DLevel& L, uint32_t i, bool active, const
         const RT_GLOBAL DObject* op = gptr(S.objects) + c.obj;
         if (!(gptr(S.materials)[op->material].emissivity == 1.)) {      // scene.rs:105-107: fully emissive = no lighting
             Hit h;
-            closest_hit_fill(S, ray, c.obj, c.rank, c.t, c.t2, c.u, c.v, h);
+            closest_hit_fill<MESHES>(S, ray, c.obj, c.rank, c.t, c.t2, c.u, c.v, h);
             vnear = h.vnear;
             so = h.vnear + h.normal * RT_EPSILON;
             lit = true;
@@ -167,7 +168,8 @@ DEV void trace_finish(const DScene& S, DLevel& L, uint32_t i, bool active, const
 #ifndef RT_TRACE_ATTR
 #define RT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(4, 8)))
 #endif
-template <bool COUNT, bool PACKET, bool BUDGET, bool FAR = true>
+// MESHES = false: a scene of analytic objects only (lane by lane, no budget): the mesh walks stay out of the kernel.
+template <bool COUNT, bool PACKET, bool BUDGET, bool FAR = true, bool MESHES = true>
 __global__ __launch_bounds__(RT_BLOCK) RT_TRACE_ATTR void k_trace(const DScene* Sp, DLevel L, uint32_t n, uint32_t* hitlist, double* hs, uint32_t stride,
                                                     DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_TRACE_ATTR void k_trace(const DScene* 
         // the wave's rays are coherent (primary rays of an 8x8 pixel block) and walk the BVH together
         hit = cast_closest_packet<FAR>(S, ray, active, c, vc);
     } else if (active && !BUDGET) {
-        hit = cast_closest<FAR>(S, ray, c, vc);
+        hit = MESHES ? cast_closest<FAR>(S, ray, c, vc) : cast_closest_analytic(S, ray, c);
     } else if (active) {
         bool aborted = false;
         hit = cast_closest_seg(S, ray, c, vc, 0, 1, lp.budget_lane, aborted);
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_TRACE_ATTR void k_trace(const DScene* 
             active = false; hit = false;
         }
     }
-    trace_finish(S, L, i, active, ray, hit, c, hitlist, hs, stride, LC);
+    trace_finish<MESHES>(S, L, i, active, ray, hit, c, hitlist, hs, stride, LC);
     if (COUNT) {
         DShard* sh = my_shard(C);
         if (PACKET) { if (lane_id() == 0) atomicMax(&sh->max_wave_steps, (unsigned long long)(vc.wnodes + vc.wtris)); }

@@ -532,7 +532,8 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
                 hipLaunchKernelGGL(kern, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters, lc, long_trace, lp);
             };
             const bool cnt = (c->count_visits & 1) != 0;
-            if (depth <= c->packet_depth && c->hscene.n_meshes > 0) {   // packets pay for mesh walks only
+            if (c->hscene.n_meshes == 0) { if (cnt) launch(k_trace<true, false, false, false, false>); else launch(k_trace<false, false, false, false, false>); }
+            else if (depth <= c->packet_depth) {   // (packets pay for mesh walks only)
                 if (c->any_need_far) { if (cnt) launch(k_trace<true, true, false, true>); else launch(k_trace<false, true, false, true>); }
                 else { if (cnt) launch(k_trace<true, true, false, false>); else launch(k_trace<false, true, false, false>); }
             }

@@ -10,5 +10,5 @@ P4="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d $R/gpurun_out/$N/p$i -o p -- python3 $R/tools/prof_frame.py "$@" > $R/gpurun_out/$N.p$i.log 2>&1 || exit 1
+  timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d $R/gpurun_out/$N/p$i -o p -- python3 $R/tools/${PROG:-prof_frame.py} "$@" > $R/gpurun_out/$N.p$i.log 2>&1 || exit 1
 done
