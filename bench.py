@@ -183,7 +183,9 @@ def main():
                   # wave_tri_steps: triangle records fetched per wave by the closest-hit packets, and rounds of 64
                   # (ray, leaf) pairs tested by the shadow packets (whose lanes fetch their own triangles)
                   "wave_node_fetches": int(cst.wave_nodes), "wave_tri_steps": int(cst.wave_tris),
-                  "node_bytes_fetched_by_waves": int(cst.wave_nodes) * 128}
+                  # B_touched: node and triangle records the walks really fetched, at their real sizes (112 / 80
+                  # bytes), a packet's shared fetch counted once
+                  "bytes_touched": int(cst.bytes_fetched)}
 
     if rank == 0:
         frame_rgb = frame.cpu().numpy().reshape(vh, vw, 3)

@@ -188,6 +188,9 @@ typedef struct rt_stats {
     uint64_t long_trace, long_shadow;
     /* instrumented contexts only: the longest walk (inner nodes + triangle tests) of one lane / of one wave packet */
     uint64_t max_lane_steps, max_wave_steps;
+    /* instrumented contexts only: bytes of BVH data (node and triangle records, at their real sizes) the walks of
+     * the last frame fetched; a packet's shared fetch counts once */
+    uint64_t bytes_fetched;
 } rt_stats;
 
 /* result of one probe ray (rt_cast_rays): the fields of object/mod.rs:18-36

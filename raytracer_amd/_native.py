@@ -32,6 +32,7 @@ class RtStats(C.Structure):
         ("launches_trace", C.c_uint32), ("launches_shadow", C.c_uint32), ("launches_shade", C.c_uint32), ("_pad", C.c_uint32),
         ("long_trace", C.c_uint64), ("long_shadow", C.c_uint64),
         ("max_lane_steps", C.c_uint64), ("max_wave_steps", C.c_uint64),
+        ("bytes_fetched", C.c_uint64),
     ]
 
     @property

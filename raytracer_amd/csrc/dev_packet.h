@@ -158,6 +158,7 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
                 double t; float u, v;
                 if (in) vc.tris++;
                 vc.wtris++;
+                if (__lane_id() == 0) vc.units += 5;
                 if (in && tri_test(T, ray, t, u, v) && (t < mh.t0 || (t == mh.t0 && rank < mh.r0))) {
                     mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v; mh.n = 1;
                     limit = __double2float_ru(t);
@@ -171,6 +172,7 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
             const UNode n = load_unode(nodes, cur);
             if (lane_in(curmask)) vc.nodes++;
             vc.wnodes++;
+            if (__lane_id() == 0) vc.units += 7;
             float t0, t1, t2, t3, f0, f1, f2, f3;
             RT_CHILD_PAIR(n, 0, t0, f0, t1, f1);
             RT_CHILD_PAIR(n, 2, t2, f2, t3, f3);
@@ -287,7 +289,7 @@ __device__ void test_pairs(const DTri* tris, uint32_t base, uint32_t cnt, Visits
             while (true) {
                 const TriData T = tri_load(gptr(tris) + rank);
                 double t; float u, v;
-                vc.tris++;
+                vc.tris++; vc.units += 5;
                 if (tri_test_od(T, ro, rd, t, u, v) && (unsigned long long)__double_as_longlong(t) < b) { qb[owner] = 0; break; }
                 if (T.last) break;
                 ++rank;
@@ -413,6 +415,7 @@ __device__ void packet_any_deferred(const DMesh& Mg, Visits& vc, uint32_t budget
                 const rt_u4 pen_z = rec[i_en_z], pex_z = rec[i_ex_z], ref = rec[6];
                 if (in_mask(inmask)) vc.nodes++;
                 vc.wnodes++;
+                if (__lane_id() == 0) vc.units += 7;
                 float t0, t1, t2, t3, f0, f1, f2, f3;
                 RT_PAIR_ENTRY_EXIT(0, t0, f0, t1, f1);
                 RT_PAIR_ENTRY_EXIT(2, t2, f2, t3, f3);

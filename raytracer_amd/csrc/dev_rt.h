@@ -273,7 +273,7 @@ struct MeshHit { double t0, t1; uint32_t r0; float u, v; uint32_t n; };   // n =
 // Per-lane traversal context: the lane's stack column in LDS, and the work the traversal really did
 // (inner-node visits = two box tests each, triangle tests); only the instrumented kernel variants store the
 // counts, elsewhere the increments are dead code.
-struct Visits { uint32_t nodes, tris; uint32_t wnodes, wtris; };   // per-lane counts; wave-level counts of the packet walk (same in every lane)
+struct Visits { uint32_t nodes, tris; uint32_t wnodes, wtris; uint32_t units; };   // units: 16-byte words of BVH data this lane fetched (a packet's shared fetches are booked on lane 0)   // per-lane counts; wave-level counts of the packet walk (same in every lane)
 
 // Traversal stack: (node reference, entry distance) pairs.  The first RT_LDS_STACK entries of every lane live
 // in LDS, laid out [entry][lane] so that a wave's push or pop touches consecutive 8-byte words (no bank
@@ -350,7 +350,7 @@ __device__ bool mesh_traverse_seg(const DMesh& M, const Ray& ray, double bound, 
         //      the triangle tests below run with as many lanes as possible)
         while (!(cur & RT_LEAF_BIT)) {
             const GNodePtr nd = &nodes[cur];
-            vc.nodes++;
+            vc.nodes++; vc.units += 7;
             if (SEG && seg.budget && ++steps > seg.budget) { aborted = true; return false; }
             float t0, t1, t2, t3;
             // near/far plane of each child on each axis, by the sign of the direction
@@ -405,7 +405,7 @@ __device__ bool mesh_traverse_seg(const DMesh& M, const Ray& ray, double bound, 
             const TriData T = tri_load(&tris[rank]);
             const uint32_t last = T.last;
             double t; float u, v;
-            vc.tris++;
+            vc.tris++; vc.units += 5;
             if (tri_test(T, ray, t, u, v)) {
                 if (MODE == TRAV_ANY) {
                     if (t <= bound) return true;

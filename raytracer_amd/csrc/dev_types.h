@@ -144,7 +144,7 @@ enum { NF_DONE = 1, NF_TRANSPARENT = 2, NF_T_REFLECT = 4, NF_REFLECT = 8, NF_EMI
 // RT_SHARDS cache lines (a workgroup adds to shard blockIdx % RT_SHARDS) because thousands of adds to ONE word
 // serialise at about 12 ns each and would cost milliseconds per frame.  The host sums the shards.
 #define RT_SHARDS 64
-struct DShard { unsigned long long rays_reflect, rays_transmit, rays_shadow, nodes_visited, tris_tested, wave_nodes, wave_tris, max_lane_steps, max_wave_steps, pad[7]; };   // 128 B
+struct DShard { unsigned long long rays_reflect, rays_transmit, rays_shadow, nodes_visited, tris_tested, wave_nodes, wave_tris, max_lane_steps, max_wave_steps, units_fetched, pad[6]; };   // 128 B
 struct DLevelCounts {
     unsigned long long next_count;   // rays this level appended to the next one
     unsigned long long hit_count;    // lit hits of this level (length of its k_shadow work list)

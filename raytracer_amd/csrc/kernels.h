@@ -174,7 +174,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_TRACE_ATTR void k_trace(const DScene* 
                                                     DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     const DScene& S = *Sp;
-    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
+    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0; vc.units = 0;
     bool active = i < n && L.hit_obj[i] != RT_INACTIVE;
     const uint32_t ii = i < n ? i : 0;
     Ray ray = load_ray(L, ii);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_TRACE_ATTR void k_trace(const DScene* 
         DShard* sh = my_shard(C);
         if (PACKET) { if (lane_id() == 0) atomicMax(&sh->max_wave_steps, (unsigned long long)(vc.wnodes + vc.wtris)); }
         else atomicMax(&sh->max_lane_steps, (unsigned long long)(vc.nodes + vc.tris));
-        block_count3(vc.nodes, vc.tris, 0, &sh->nodes_visited, &sh->tris_tested, nullptr);
+        block_count3(vc.nodes, vc.tris, vc.units, &sh->nodes_visited, &sh->tris_tested, &sh->units_fetched);
         block_count3(lane_id() == 0 ? vc.wnodes : 0, lane_id() == 0 ? vc.wtris : 0, 0, &sh->wave_nodes, &sh->wave_tris, nullptr);
     }
 }
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_long_trace(const DScene* Sp, DLeve
     const DScene& S = *Sp;
     const uint32_t n_long = (uint32_t)LC->long_trace;
     const uint32_t per_block = RT_BLOCK / RT_SEGS;
-    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
+    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0; vc.units = 0;
     for (uint32_t base = blockIdx.x * per_block; base < n_long; base += gridDim.x * per_block) {   // uniform per block
         const uint32_t j = base + threadIdx.x / RT_SEGS, k = threadIdx.x % RT_SEGS;
         const bool have = j < n_long;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_long_trace(const DScene* Sp, DLeve
         }
         trace_finish(S, L, i, have && k == 0, ray, hit, c, hitlist, hs, stride, LC);
     }
-    if (COUNT) { DShard* sh = my_shard(C); block_count3(vc.nodes, vc.tris, 0, &sh->nodes_visited, &sh->tris_tested, nullptr); }
+    if (COUNT) { DShard* sh = my_shard(C); block_count3(vc.nodes, vc.tris, vc.units, &sh->nodes_visited, &sh->tris_tested, &sh->units_fetched); }
 }
 
 // The shadow ray of lit hit `hh` towards light `Lt` (sun.rs:87-94, point.rs:68-76,89-99).  cast = 0: the light casts
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene
     const uint32_t h = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t li = blockIdx.y;
     const DScene& S = *Sp;
-    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
+    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0; vc.units = 0;
     uint32_t cast = 0;
     const bool have = h < (uint32_t)LC->hit_count;
     if (__ballot(have)) {   // the grid is sized for the worst case: most waves past the hit count have nothing to do
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene
     if (COUNT) {
         if (lane_id() == 0) atomicMax(&sh->max_wave_steps, (unsigned long long)(vc.wnodes + vc.wtris));
         block_count3(cast, vc.nodes, vc.tris, &sh->rays_shadow, &sh->nodes_visited, &sh->tris_tested);
-        block_count3(lane_id() == 0 ? vc.wnodes : 0, lane_id() == 0 ? vc.wtris : 0, 0, &sh->wave_nodes, &sh->wave_tris, nullptr);
+        block_count3(lane_id() == 0 ? vc.wnodes : 0, lane_id() == 0 ? vc.wtris : 0, vc.units, &sh->wave_nodes, &sh->wave_tris, &sh->units_fetched);
     } else block_count3(cast, 0, 0, &sh->rays_shadow, nullptr, nullptr);
 }
 
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_long_shadow(const DScene* Sp, cons
     const DScene& S = *Sp;
     const uint32_t n_long = (uint32_t)LC->long_shadow;
     const uint32_t per_block = RT_BLOCK / RT_SEGS;
-    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
+    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0; vc.units = 0;
     for (uint32_t base = blockIdx.x * per_block; base < n_long; base += gridDim.x * per_block) {
         const uint32_t j = base + threadIdx.x / RT_SEGS, k = threadIdx.x % RT_SEGS;
         if (j >= n_long) continue;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_long_shadow(const DScene* Sp, cons
         const Ray ray = shadow_ray(gptr(S.lights) + li, hs, stride, hh, cast, limited, dist);
         if (cast && cast_any_seg(S, ray, limited, dist, vc, k, RT_SEGS)) occ[(size_t)li * stride + hitlist[hh]] = 1;
     }
-    if (COUNT) { DShard* sh = my_shard(C); block_count3(vc.nodes, vc.tris, 0, &sh->nodes_visited, &sh->tris_tested, nullptr); }
+    if (COUNT) { DShard* sh = my_shard(C); block_count3(vc.nodes, vc.tris, vc.units, &sh->nodes_visited, &sh->tris_tested, &sh->units_fetched); }
 }
 
 // One light's contribution (lighting/sun.rs:72-97, point.rs:66-105) given its shadow cast's result
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_spawn(const DScene* Sp, DLevel L, 
         if (ids_out && depth == 0) { ids_out[2 * (size_t)i] = RT_NONE; ids_out[2 * (size_t)i + 1] = RT_NONE; }
         active = false;
     }
-    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
+    Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0; vc.units = 0;
     bool want0 = false, want1 = false, pending = false;
     D3 c0o = d3(0, 0, 0), c0d = d3(0, 0, 1), c1o = d3(0, 0, 0), c1d = d3(0, 0, 1);
 
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_spawn(const DScene* Sp, DLevel L, 
     if (want1) { store_ray(N, s1, c1o, c1d); N.hit_obj[s1] = RT_NONE; }
     DShard* sh = my_shard(C);
     block_count3(want0 ? 1u : 0u, want1 ? 1u : 0u, 0, &sh->rays_transmit, &sh->rays_reflect, nullptr);
-    if (COUNT) block_count3(vc.nodes, vc.tris, 0, &sh->nodes_visited, &sh->tris_tested, nullptr);
+    if (COUNT) block_count3(vc.nodes, vc.tris, vc.units, &sh->nodes_visited, &sh->tris_tested, &sh->units_fetched);
 }
 
 // The lit colour of every hit that k_spawn left pending (scene.rs:102-122), from the shadow casts' results.  A hit
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(const DScene* Sp, const doub
     bool any = false; uint32_t best = RT_NONE; Hit bh;
     for (uint32_t oi = 0; oi < S.n_objects; oi++) {
         Hit h;
-        Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0;
+        Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0; vc.units = 0;
         if (object_intersect(S, oi, ray, h, vc) && (!any || h.near < bh.near)) { any = true; best = oi; bh = h; }
     }
     if (any) {

@@ -630,6 +630,7 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
         stats.rays_reflect += sh.rays_reflect; stats.rays_transmit += sh.rays_transmit; stats.rays_shadow += sh.rays_shadow;
         stats.nodes_visited += sh.nodes_visited; stats.tris_tested += sh.tris_tested;
         stats.wave_nodes += sh.wave_nodes; stats.wave_tris += sh.wave_tris;
+        stats.bytes_fetched += 16ull * sh.units_fetched;
         stats.max_lane_steps = std::max<uint64_t>(stats.max_lane_steps, sh.max_lane_steps); stats.max_wave_steps = std::max<uint64_t>(stats.max_wave_steps, sh.max_wave_steps);
     }
     stats.ms_render = ms_all; stats.ms_trace = ms_trace; stats.ms_shadow = ms_shadow; stats.ms_shade = ms_shade; stats.ms_resolve = ms_resolve;
