@@ -98,6 +98,10 @@ def gather_frame(local, vw, vh, rank, world, detile):
         dist.gather(local, gather_list=list(buf.chunk(world)), dst=0)
         return detile(buf)
     dist.gather(local, gather_list=None, dst=0)
+    if local.is_cuda:
+        # the send is only queued when gather returns; the caller renders the next frame into `local` on another
+        # stream as soon as it has the buffer back, so hand it back only once the send has left it
+        torch.cuda.current_stream(local.device).synchronize()
     return None
 
 
