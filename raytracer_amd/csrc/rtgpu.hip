@@ -66,6 +66,10 @@ struct rt_ctx {
     DLevelCounts* d_lcounts = nullptr;                // [n_lcounts], one pair of cursors per level
     DLevelCounts* h_lcounts = nullptr;                // pinned
     size_t n_lcounts = 0;
+    // Streams in use (RTGPU_SIDE_STREAMS lowers it).  A context has 1 + n_side streams; when the streams of all the contexts
+    // of a process outnumber its hardware queues (GPU_MAX_HW_QUEUES), some share a queue and run one after the other: a
+    // pipeline of 4 contexts that shares unluckily is 15 % slower.  4 contexts x 5 streams want 24 queues.
+    uint32_t n_side = RT_SIDE_STREAMS;
     hipStream_t side[RT_SIDE_STREAMS] = {nullptr, nullptr, nullptr, nullptr};   // shadow + lighting of level d runs on side[d % N]
     LongParams long_params = {0u, 256u};              // walk budgets (inner nodes per lane / per wave) before a ray goes on the long-ray list; 0 = off
     bool any_need_far = false;                        // some mesh's material needs Hit::far (transparency with ior == 1)
@@ -522,7 +526,7 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
         // launch the other waves hide a long walk, and cutting it up would only add work
         LongParams lp = c->long_params;
         if (n >= c->long_below) { lp.budget_lane = 0; lp.budget_wave = 0; }
-        hipStream_t side = c->serial ? s : c->side[depth % RT_SIDE_STREAMS];
+        hipStream_t side = c->serial ? s : c->side[depth % c->n_side];
         const dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
         HIP_TRY(c, hipEventRecord(W.ev[LW_T0], s));
         // depth 0 of a scene with meshes: primary rays, 8x8 pixel blocks per wave -> coherent packets; deeper rays
@@ -588,7 +592,7 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
         HIP_TRY(c, hipGetLastError());
         const unsigned long long spawned = c->h_lcounts[depth].next_count;
         if (spawned > next_cap) {
-            for (auto side_s : c->side) (void)hipStreamSynchronize(side_s);
+            for (auto side_s : c->side) if (side_s) (void)hipStreamSynchronize(side_s);
             return fail(c, RT_ERR_DEVICE, "wavefront level overflow");
         }
         if (spawned > 0 && can_spawn) {
@@ -681,7 +685,8 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
     // (all streams at the default priority: mixed priorities hung the frame on this ROCm)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-    for (auto& ss : c->side) if ((e = hipStreamCreateWithFlags(&ss, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if (const char* b = std::getenv("RTGPU_SIDE_STREAMS")) c->n_side = std::min<uint32_t>(RT_SIDE_STREAMS, std::max<uint32_t>(1, (uint32_t)std::strtoul(b, nullptr, 10)));
+    for (uint32_t k = 0; k < c->n_side; k++) if ((e = hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipMalloc((void**)&c->dscene, sizeof(DScene))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->dcounters, sizeof(DCounters))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipHostMalloc((void**)&c->hcounters, sizeof(DCounters), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);

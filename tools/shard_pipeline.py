@@ -5,6 +5,7 @@ import sys
 import threading
 import time
 
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_HW_QUEUES", "24")   # as bench.py: every stream of every context on a queue of its own
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import raytracer_amd as ra  # noqa: E402
