@@ -200,6 +200,38 @@ def test_sharded_renderer_world1(gpu_ctx):
     assert np.array_equal(frame.cpu().numpy().reshape(60, 100, 3), whole)
 
 
+def test_frames_in_flight_come_back_in_order_and_equal(gpu_ctx):
+    """the bench's path: several contexts, one host thread each, frames delivered in order (sequence mode,
+    sdl/src/main.rs:70-95); every frame of the pipeline equals the frame one context renders alone"""
+    import torch
+    s = scenes.small_mixed_scene(150, 85, cells=8)
+    gpu_ctx.upload(s)
+    whole, _, st0 = gpu_ctx.render()
+
+    def make_context():
+        c = ra.Context(0)
+        c.upload(s)
+        return c
+
+    pipe = rd.FramePipeline(make_context, 0, 1, torch.device("cuda:0"), depth=3)
+    try:
+        seen = []
+
+        def on_frame(f, st, frame):
+            seen.append(f)
+            assert st.rays == st0.rays
+            assert np.array_equal(frame.cpu().numpy().reshape(85, 150, 3), whole)
+
+        stats = pipe.run(8, on_frame)
+        assert seen == list(range(8)) and len(stats) == 8
+        # a second run on the same pipeline (the bench warms up, then times)
+        seen.clear()
+        pipe.run(2, on_frame)
+        assert seen == [0, 1]
+    finally:
+        pipe.close()
+
+
 def test_reupload_sequence_and_determinism(gpu_ctx):
     """sdl/src/main.rs:84-92 re-renders a changed scene per frame through one context"""
     frames = []
