@@ -210,7 +210,12 @@ def main():
             gbs = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             kernels[name] = {"avg_launch_ms": avg_ms, "launches_per_frame": n_l / max(args.steps, 1), "bytes_per_launch": bytes_launch,
                              "GB/s": gbs, "ms_per_frame": ms / max(args.steps, 1)}
-        dom = max(per_kernel, key=lambda k: per_kernel[k][1])
+        # The dominant kernel: the one that owns most of the frame's algorithmic bytes (the shadow casts: 8 per lit hit).
+        # Launch durations cannot decide it: the launches of different kernels overlap (side streams, frames in flight),
+        # each stretches by what it waits for the others, and the order of two sums flips from run to run.  With the
+        # kernels of a frame run one after the other (RTGPU_SERIAL=1, tools/prof_frame.py) it is the same kernel: 60 %
+        # of the frame's kernel time.
+        dom = max(per_kernel, key=lambda k: per_kernel[k][0])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
