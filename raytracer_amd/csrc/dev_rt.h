@@ -519,6 +519,11 @@ DEV bool tlas_object_near(const DScene& S, uint32_t oi, const Ray& ray, double& 
     if (kind == 0) return sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
     return box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
 }
+DEV bool tlas_leaf_near(const DScene& S, uint32_t what, const Ray& ray, double& near) {
+    const uint32_t payload = what & ~RT_TLAS_BOX;
+    if (!(what & RT_TLAS_BOX)) return sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
+    return box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
+}
 // cast_ray_once over the tree's objects: nearest by `near`, ties to the lower object index (scene.rs:57-82); `c` may
 // already hold the best of the objects outside the tree
 __device__ bool tlas_closest(const DScene& S, const Ray& ray, Closest& c, bool any) {
@@ -571,9 +576,9 @@ __device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c
     float tn_root = -INF;
     if (cull && !(node_box(nodes[0].bmin, nodes[0].bmax, ray, tn_root) && !(tn_root > limit))) return any;
     // an object reached through a leaf reference: nearest by `near`, ties to the lower index
-    auto object = [&](uint32_t oi) {
+    auto object = [&](uint32_t oi, uint32_t what) {
         double near;
-        if (tlas_object_near(S, oi, ray, near) && (!any || near < c.t || (near == c.t && oi < c.obj))) {
+        if (tlas_leaf_near(S, what, ray, near) && (!any || near < c.t || (near == c.t && oi < c.obj))) {
             c.obj = oi; c.rank = RT_NONE; c.t = near; c.t2 = 0.; c.u = 0.f; c.v = 0.f; any = true;
             limit = __double2float_ru(near);
         }
@@ -592,8 +597,8 @@ __device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c
             hr = node_box(W.rmin, W.rmax, ray, tr) && !(tr > limit);
         }
         // leaves are tested on the spot; what they find may close the other child
-        if (hl && (W.left & RT_TLAS_LEAF)) { object(W.left & ~RT_TLAS_LEAF); hl = false; }
-        if (hr && (W.right & RT_TLAS_LEAF)) { if (!(tr > limit)) object(W.right & ~RT_TLAS_LEAF); hr = false; }
+        if (hl && (W.left & RT_TLAS_LEAF)) { object(W.left & ~RT_TLAS_LEAF, W.lwhat); hl = false; }
+        if (hr && (W.right & RT_TLAS_LEAF)) { if (!(tr > limit)) object(W.right & ~RT_TLAS_LEAF, W.rwhat); hr = false; }
         if (hl && tl > limit) hl = false;
         if (hr && tr > limit) hr = false;
         if (hl && hr) {
@@ -764,11 +769,11 @@ __device__ bool tlas_any_ordered(const DScene& S, const Ray& ray, bool limited, 
         }
         double near;
         if (hl && (W.left & RT_TLAS_LEAF)) {
-            if (tlas_object_near(S, W.left & ~RT_TLAS_LEAF, ray, near) && (!limited || near <= dist)) return true;
+            if (tlas_leaf_near(S, W.lwhat, ray, near) && (!limited || near <= dist)) return true;
             hl = false;
         }
         if (hr && (W.right & RT_TLAS_LEAF)) {
-            if (tlas_object_near(S, W.right & ~RT_TLAS_LEAF, ray, near) && (!limited || near <= dist)) return true;
+            if (tlas_leaf_near(S, W.rwhat, ray, near) && (!limited || near <= dist)) return true;
             hr = false;
         }
         if (hl && hr) {

@@ -75,9 +75,11 @@ struct DTlasNode {
 struct __attribute__((aligned(16))) DTlasWide {
     float lmin[3], lmax[3], rmin[3], rmax[3];
     uint32_t left, right;
-    uint32_t pad[2];
+    uint32_t lwhat, rwhat;     // for a leaf child: RT_TLAS_BOX | index into DScene::boxes, or the index into DScene::spheres
+                               // (what DScene::objects would say about the object, without the dependent fetch)
 };
 #define RT_TLAS_LEAF 0x80000000u
+#define RT_TLAS_BOX 0x40000000u
 
 struct DMaterial {
     uint32_t tex_kind;

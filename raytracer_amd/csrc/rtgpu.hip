@@ -854,7 +854,9 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
                 for (int k = 0; k < 3; k++) { it.lo[k] = b.pos[k] - std::fabs(b.half[k]); it.hi[k] = b.pos[k] + std::fabs(b.half[k]); }
             } else continue;
             for (int k = 0; k < 3; k++) finite = finite && std::isfinite(it.lo[k]) && std::isfinite(it.hi[k]);
-            if (finite) items.push_back(it);   // an object with a NaN / infinite extent stays in the linear scan
+            // an object with a NaN / infinite extent stays in the linear scan (and so does one whose index would not fit
+            // beside the flag bit of a leaf record)
+            if (finite && o.payload < RT_TLAS_BOX) items.push_back(it);
         }
         uint32_t tlas_min = 8;
         if (const char* e = std::getenv("RTGPU_TLAS_MIN")) tlas_min = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -882,6 +884,9 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
                 }
                 w.left = (nodes[l].object & RT_TLAS_INNER) ? wide_of[l] : (RT_TLAS_LEAF | nodes[l].object);
                 w.right = (nodes[r].object & RT_TLAS_INNER) ? wide_of[r] : (RT_TLAS_LEAF | nodes[r].object);
+                auto what = [&](uint32_t oi) { return (objs[oi].kind == RT_OBJ_BOX ? RT_TLAS_BOX : 0u) | objs[oi].payload; };
+                if (w.left & RT_TLAS_LEAF) w.lwhat = what(nodes[l].object);
+                if (w.right & RT_TLAS_LEAF) w.rwhat = what(nodes[r].object);
             }
             if ((rc = upload(c, wide.data(), wide.size(), &H.tlas_wide)) != RT_OK) return rc;
         }
