@@ -562,12 +562,42 @@ __device__ bool tlas_any(const DScene& S, const Ray& ray, bool limited, double d
     }
     return false;
 }
-// tlas_closest for the kernels that own a per-lane stack (the lane-by-lane trace kernels): nearer child first, so
-// that the nearest object is found early and the boxes behind it are never entered.  Same answer as the skip-link
-// walk: every object whose box the ray enters before the best distance is tested, ties go to the lower index.
+// One child of a four-wide record: its entry distance if the ray enters its box no later than `limit`, +inf if not (or
+// if the slot is unused); without culling every child counts as entered at -inf.
+#define RT_TQ_CHILD(k, t_)                                                                                                   \
+    do {                                                                                                                     \
+        if (W.ref[k] == RT_TLAS_NONE) (t_) = INF;                                                                            \
+        else if (!cull) (t_) = -INF;                                                                                         \
+        else {                                                                                                               \
+            float tn_;                                                                                                       \
+            const bool h_ = slab_test(ray.nx ? W.maxx[k] : W.minx[k], ray.ny ? W.maxy[k] : W.miny[k], ray.nz ? W.maxz[k] : W.minz[k], \
+                                      ray.nx ? W.minx[k] : W.maxx[k], ray.ny ? W.miny[k] : W.maxy[k], ray.nz ? W.minz[k] : W.maxz[k], ray, tn_); \
+            (t_) = (h_ && !(tn_ > limit)) ? tn_ : INF;                                                                       \
+        }                                                                                                                    \
+    } while (0)
+// compare-exchange of (distance, reference, leaf word) triples: afterwards ta <= tb
+#define RT_CSWAP3(ta, ra, wa, tb, rb, wb)                                     \
+    do {                                                                      \
+        const bool sw_ = (tb) < (ta);                                         \
+        const float tx_ = sw_ ? (tb) : (ta), ty_ = sw_ ? (ta) : (tb);         \
+        const uint32_t rx_ = sw_ ? (rb) : (ra), ry_ = sw_ ? (ra) : (rb);      \
+        const uint32_t wx_ = sw_ ? (wb) : (wa), wy_ = sw_ ? (wa) : (wb);      \
+        (ta) = tx_; (tb) = ty_; (ra) = rx_; (rb) = ry_; (wa) = wx_; (wb) = wy_; \
+    } while (0)
+#define RT_TQ_LOAD(cur_)                                                                      \
+    const RT_GLOBAL rt_d2* p_ = (const RT_GLOBAL rt_d2*)(quads + (cur_));                     \
+    union { rt_d2 q[8]; DTlasQuad w; } rec;                                                   \
+    rec.q[0] = p_[0]; rec.q[1] = p_[1]; rec.q[2] = p_[2]; rec.q[3] = p_[3];                   \
+    rec.q[4] = p_[4]; rec.q[5] = p_[5]; rec.q[6] = p_[6]; rec.q[7] = p_[7];                   \
+    const DTlasQuad& W = rec.w
+
+// tlas_closest for the kernels that own a per-lane stack (the lane-by-lane trace kernels): the four-wide records,
+// nearer children first, so that the nearest object is found early and the boxes behind it are never entered.  Same
+// answer as the skip-link walk: every object whose box the ray enters before the best distance is tested, ties go to
+// the lower index.
 __device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c, bool any) {
     const RT_GLOBAL DTlasNode* nodes = (const RT_GLOBAL DTlasNode*)S.tlas;
-    const RT_GLOBAL DTlasWide* wide = (const RT_GLOBAL DTlasWide*)S.tlas_wide;
+    const RT_GLOBAL DTlasQuad* quads = (const RT_GLOBAL DTlasQuad*)S.tlas_quad;
     const bool cull = tlas_culls(ray);
     const float INF = __uint_as_float(0x7F800000u);
     int sp = 0;
@@ -585,28 +615,25 @@ __device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c
     };
     uint32_t cur = 0;
     while (true) {
-        // one record: both children's boxes (four 16-byte loads)
-        const RT_GLOBAL rt_d2* p = (const RT_GLOBAL rt_d2*)(wide + cur);
-        union { rt_d2 q[4]; DTlasWide w; } rec;
-        rec.q[0] = p[0]; rec.q[1] = p[1]; rec.q[2] = p[2]; rec.q[3] = p[3];
-        const DTlasWide& W = rec.w;
-        float tl = -INF, tr = -INF;
-        bool hl = true, hr = true;
-        if (cull) {
-            hl = node_box(W.lmin, W.lmax, ray, tl) && !(tl > limit);
-            hr = node_box(W.rmin, W.rmax, ray, tr) && !(tr > limit);
-        }
-        // leaves are tested on the spot; what they find may close the other child
-        if (hl && (W.left & RT_TLAS_LEAF)) { object(W.left & ~RT_TLAS_LEAF, W.lwhat); hl = false; }
-        if (hr && (W.right & RT_TLAS_LEAF)) { if (!(tr > limit)) object(W.right & ~RT_TLAS_LEAF, W.rwhat); hr = false; }
-        if (hl && tl > limit) hl = false;
-        if (hr && tr > limit) hr = false;
-        if (hl && hr) {
-            const bool left_first = !(tr < tl);
-            if (sp >= RT_MAX_STACK) return any;   // cannot happen: a median-split tree over < 2^31 objects is < 32 deep
-            RT_STACK_PUSH(left_first ? W.right : W.left, left_first ? tr : tl);
-            cur = left_first ? W.left : W.right;
-        } else cur = hl ? W.left : hr ? W.right : RT_POP;
+        RT_TQ_LOAD(cur);
+        float t0, t1, t2, t3;
+        RT_TQ_CHILD(0, t0); RT_TQ_CHILD(1, t1); RT_TQ_CHILD(2, t2); RT_TQ_CHILD(3, t3);
+        uint32_t r0 = W.ref[0], r1 = W.ref[1], r2 = W.ref[2], r3 = W.ref[3];
+        uint32_t w0 = W.what[0], w1 = W.what[1], w2 = W.what[2], w3 = W.what[3];
+        RT_CSWAP3(t0, r0, w0, t1, r1, w1); RT_CSWAP3(t2, r2, w2, t3, r3, w3);
+        RT_CSWAP3(t0, r0, w0, t2, r2, w2); RT_CSWAP3(t1, r1, w1, t3, r3, w3);
+        RT_CSWAP3(t1, r1, w1, t2, r2, w2);
+        // leaves are tested on the spot, nearest first; what they find may close the children behind them
+#define RT_TQ_LEAF(t_, r_, w_) if ((t_) < INF && ((r_) & RT_TLAS_LEAF)) { if (!((t_) > limit)) object((r_) & ~RT_TLAS_LEAF, (w_)); (t_) = INF; }
+        RT_TQ_LEAF(t0, r0, w0) RT_TQ_LEAF(t1, r1, w1) RT_TQ_LEAF(t2, r2, w2) RT_TQ_LEAF(t3, r3, w3)
+#undef RT_TQ_LEAF
+        // the inner children still open, farthest first: the nearest is walked next, the others wait on the stack
+        if (sp + 3 > RT_MAX_STACK) return any;   // cannot happen: upload refuses a tree this deep
+        cur = RT_POP;
+        float cur_t = INF;
+#define RT_TQ_INNER(t_, r_) if ((t_) < INF && !((t_) > limit)) { if (cur != RT_POP) RT_STACK_PUSH(cur, cur_t); cur = (r_); cur_t = (t_); }
+        RT_TQ_INNER(t3, r3) RT_TQ_INNER(t2, r2) RT_TQ_INNER(t1, r1) RT_TQ_INNER(t0, r0)
+#undef RT_TQ_INNER
         if (cur == RT_POP) {
             while (sp > 0) {
                 uint2 e;
@@ -743,11 +770,10 @@ __device__ bool cast_any_seg(const DScene& S, const Ray& ray, bool limited, doub
     return S.n_tlas != 0 && tlas_any(S, ray, limited, dist);
 }
 
-// tlas_any for a kernel that owns a per-lane stack: the wide records, nearer child first (a blocker near the ray's
-// start ends the walk early), nothing beyond `dist` entered.
+// tlas_any for a kernel that owns a per-lane stack: the four-wide records, nothing beyond `dist` entered.
 __device__ bool tlas_any_ordered(const DScene& S, const Ray& ray, bool limited, double dist) {
     const RT_GLOBAL DTlasNode* nodes = (const RT_GLOBAL DTlasNode*)S.tlas;
-    const RT_GLOBAL DTlasWide* wide = (const RT_GLOBAL DTlasWide*)S.tlas_wide;
+    const RT_GLOBAL DTlasQuad* quads = (const RT_GLOBAL DTlasQuad*)S.tlas_quad;
     const bool cull = tlas_culls(ray);
     const float INF = __uint_as_float(0x7F800000u);
     int sp = 0;
@@ -757,31 +783,23 @@ __device__ bool tlas_any_ordered(const DScene& S, const Ray& ray, bool limited, 
     if (cull && !(node_box(nodes[0].bmin, nodes[0].bmax, ray, tn_root) && !(tn_root > limit))) return false;
     uint32_t cur = 0;
     while (true) {
-        const RT_GLOBAL rt_d2* p = (const RT_GLOBAL rt_d2*)(wide + cur);
-        union { rt_d2 q[4]; DTlasWide w; } rec;
-        rec.q[0] = p[0]; rec.q[1] = p[1]; rec.q[2] = p[2]; rec.q[3] = p[3];
-        const DTlasWide& W = rec.w;
-        float tl = -INF, tr = -INF;
-        bool hl = true, hr = true;
-        if (cull) {
-            hl = node_box(W.lmin, W.lmax, ray, tl) && !(tl > limit);
-            hr = node_box(W.rmin, W.rmax, ray, tr) && !(tr > limit);
-        }
+        RT_TQ_LOAD(cur);
+        float t0, t1, t2, t3;
+        RT_TQ_CHILD(0, t0); RT_TQ_CHILD(1, t1); RT_TQ_CHILD(2, t2); RT_TQ_CHILD(3, t3);
         double near;
-        if (hl && (W.left & RT_TLAS_LEAF)) {
-            if (tlas_leaf_near(S, W.lwhat, ray, near) && (!limited || near <= dist)) return true;
-            hl = false;
+#define RT_TQ_LEAF(k, t_)                                                                                   \
+        if ((t_) < INF && (W.ref[k] & RT_TLAS_LEAF)) {                                                      \
+            if (tlas_leaf_near(S, W.what[k], ray, near) && (!limited || near <= dist)) return true;         \
+            (t_) = INF;                                                                                     \
         }
-        if (hr && (W.right & RT_TLAS_LEAF)) {
-            if (tlas_leaf_near(S, W.rwhat, ray, near) && (!limited || near <= dist)) return true;
-            hr = false;
-        }
-        if (hl && hr) {
-            const bool left_first = !(tr < tl);
-            if (sp >= RT_MAX_STACK) return false;   // cannot happen: a median-split tree over < 2^31 objects is < 32 deep
-            RT_STACK_PUSH(left_first ? W.right : W.left, 0.f);
-            cur = left_first ? W.left : W.right;
-        } else cur = hl ? W.left : hr ? W.right : RT_POP;
+        RT_TQ_LEAF(0, t0) RT_TQ_LEAF(1, t1) RT_TQ_LEAF(2, t2) RT_TQ_LEAF(3, t3)
+#undef RT_TQ_LEAF
+        // the inner children entered, in the record's order (sorting them by distance costs more than it saves here)
+        if (sp + 3 > RT_MAX_STACK) return false;   // cannot happen: upload refuses a tree this deep
+        cur = RT_POP;
+#define RT_TQ_INNER(k, t_) if ((t_) < INF) { if (cur != RT_POP) RT_STACK_PUSH(cur, 0.f); cur = W.ref[k]; }
+        RT_TQ_INNER(3, t3) RT_TQ_INNER(2, t2) RT_TQ_INNER(1, t1) RT_TQ_INNER(0, t0)
+#undef RT_TQ_INNER
         if (cur == RT_POP) {
             if (sp == 0) break;
             uint2 e;
@@ -791,6 +809,8 @@ __device__ bool tlas_any_ordered(const DScene& S, const Ray& ray, bool limited, 
     }
     return false;
 }
+#undef RT_TQ_CHILD
+#undef RT_TQ_LOAD
 
 // Shadow cast of one lane in a scene without meshes (sun.rs:89: any object the ray hits at all; point.rs:91-92: the
 // nearest hit has near <= dist, i.e. some object has near <= dist).

@@ -69,16 +69,20 @@ struct DTlasNode {
 };
 #define RT_TLAS_INNER 0x80000000u
 
-// The same tree for the walks that own a stack (the lane-by-lane trace kernels): one 64-byte record per inner node
-// with the boxes of BOTH children, so a level of the tree costs one dependent fetch instead of two, and leaves need no
-// record at all (a child reference is RT_TLAS_LEAF | object index, or the index of the child's own record).
-struct __attribute__((aligned(16))) DTlasWide {
-    float lmin[3], lmax[3], rmin[3], rmax[3];
-    uint32_t left, right;
-    uint32_t lwhat, rwhat;     // for a leaf child: RT_TLAS_BOX | index into DScene::boxes, or the index into DScene::spheres
-                               // (what DScene::objects would say about the object, without the dependent fetch)
+// The same tree for the walks that own a stack (the lane-by-lane trace kernels), folded four-wide: one 128-byte record
+// holds the boxes of up to four children (an inner node's two children, each replaced by its own two where it has
+// them), so a step of the walk covers two levels of the binary tree with one dependent fetch, and leaves need no
+// record at all.  A child reference is RT_TLAS_LEAF | object index, the index of the child's own record, or
+// RT_TLAS_NONE for an unused slot.  For a leaf child `what` says what DScene::objects would (RT_TLAS_BOX | index into
+// DScene::boxes, or the index into DScene::spheres), which saves the dependent fetch of the object record.
+struct __attribute__((aligned(16))) DTlasQuad {
+    float minx[4], miny[4], minz[4];
+    float maxx[4], maxy[4], maxz[4];
+    uint32_t ref[4];
+    uint32_t what[4];
 };
 #define RT_TLAS_LEAF 0x80000000u
+#define RT_TLAS_NONE 0xFFFFFFFFu
 #define RT_TLAS_BOX 0x40000000u
 
 struct DMaterial {
@@ -115,7 +119,7 @@ struct DScene {
     const double* boxes;            // [n][6] pos, half
     const DMesh* meshes;
     const DTlasNode* tlas;          // null when the scene has few analytic objects
-    const DTlasWide* tlas_wide;     // the inner nodes of the same tree, two child boxes each (record 0 = the root)
+    const DTlasQuad* tlas_quad;     // the same tree folded four-wide (record 0 = the root)
     const uint32_t* linear;         // indices of the objects the casts scan one by one (all that are not in the tree)
     uint32_t n_tlas, n_linear;
     const DMaterial* materials;

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -860,7 +861,7 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
         }
         uint32_t tlas_min = 8;
         if (const char* e = std::getenv("RTGPU_TLAS_MIN")) tlas_min = (uint32_t)std::strtoul(e, nullptr, 10);
-        H.tlas = nullptr; H.tlas_wide = nullptr; H.n_tlas = 0;
+        H.tlas = nullptr; H.tlas_quad = nullptr; H.n_tlas = 0;
         if (items.size() >= std::max<uint32_t>(tlas_min, 2)) {
             std::vector<DTlasNode> nodes;
             nodes.reserve(items.size() * 2);
@@ -868,27 +869,41 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
             for (const TlasItem& it : items) objs[it.object].need_far |= RT_IN_TLAS;
             if ((rc = upload(c, nodes.data(), nodes.size(), &H.tlas)) != RT_OK) return rc;
             H.n_tlas = (uint32_t)nodes.size();
-            // the wide records: inner nodes in the order they appear (so the root is record 0)
-            std::vector<uint32_t> wide_of(nodes.size(), 0);
-            uint32_t n_wide = 0;
-            for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].object & RT_TLAS_INNER) wide_of[i] = n_wide++;
-            std::vector<DTlasWide> wide(n_wide);
-            for (size_t i = 0; i < nodes.size(); i++) {
-                if (!(nodes[i].object & RT_TLAS_INNER)) continue;
-                DTlasWide& w = wide[wide_of[i]];
-                std::memset(&w, 0, sizeof(w));
-                const size_t l = i + 1, r = nodes[i].object & ~RT_TLAS_INNER;
-                for (int k = 0; k < 3; k++) {
-                    w.lmin[k] = nodes[l].bmin[k]; w.lmax[k] = nodes[l].bmax[k];
-                    w.rmin[k] = nodes[r].bmin[k]; w.rmax[k] = nodes[r].bmax[k];
+            // the four-wide records: an inner node's two children, each replaced by its own two where it has them
+            std::vector<DTlasQuad> quads;
+            uint32_t quad_depth = 0;
+            auto is_inner = [&](size_t i) { return (nodes[i].object & RT_TLAS_INNER) != 0; };
+            std::function<uint32_t(size_t, uint32_t)> fold = [&](size_t i, uint32_t depth) -> uint32_t {
+                const uint32_t q = (uint32_t)quads.size();
+                quads.emplace_back();
+                quad_depth = std::max(quad_depth, depth);
+                size_t kids[4]; int nk = 0;
+                const size_t pair[2] = {i + 1, (size_t)(nodes[i].object & ~RT_TLAS_INNER)};
+                for (size_t ch : pair) {
+                    if (is_inner(ch)) { kids[nk++] = ch + 1; kids[nk++] = nodes[ch].object & ~RT_TLAS_INNER; }
+                    else kids[nk++] = ch;
                 }
-                w.left = (nodes[l].object & RT_TLAS_INNER) ? wide_of[l] : (RT_TLAS_LEAF | nodes[l].object);
-                w.right = (nodes[r].object & RT_TLAS_INNER) ? wide_of[r] : (RT_TLAS_LEAF | nodes[r].object);
-                auto what = [&](uint32_t oi) { return (objs[oi].kind == RT_OBJ_BOX ? RT_TLAS_BOX : 0u) | objs[oi].payload; };
-                if (w.left & RT_TLAS_LEAF) w.lwhat = what(nodes[l].object);
-                if (w.right & RT_TLAS_LEAF) w.rwhat = what(nodes[r].object);
-            }
-            if ((rc = upload(c, wide.data(), wide.size(), &H.tlas_wide)) != RT_OK) return rc;
+                DTlasQuad rec;
+                std::memset(&rec, 0, sizeof(rec));
+                for (int k = 0; k < 4; k++) rec.ref[k] = RT_TLAS_NONE;
+                for (int k = 0; k < nk; k++) {
+                    const DTlasNode& nd = nodes[kids[k]];
+                    rec.minx[k] = nd.bmin[0]; rec.miny[k] = nd.bmin[1]; rec.minz[k] = nd.bmin[2];
+                    rec.maxx[k] = nd.bmax[0]; rec.maxy[k] = nd.bmax[1]; rec.maxz[k] = nd.bmax[2];
+                    if (is_inner(kids[k])) rec.ref[k] = fold(kids[k], depth + 1);
+                    else {
+                        const uint32_t oi = nd.object;
+                        rec.ref[k] = RT_TLAS_LEAF | oi;
+                        rec.what[k] = (objs[oi].kind == RT_OBJ_BOX ? RT_TLAS_BOX : 0u) | objs[oi].payload;
+                    }
+                }
+                quads[q] = rec;
+                return q;
+            };
+            fold(0, 1);
+            // a step of the walk leaves at most three children waiting
+            if (3 * (size_t)quad_depth > RT_MAX_STACK) return fail(c, RT_ERR_UNSUPPORTED, "object tree deeper than the traversal stack");
+            if ((rc = upload(c, quads.data(), quads.size(), &H.tlas_quad)) != RT_OK) return rc;
         }
     }
     if ((rc = upload(c, objs.data(), objs.size(), &H.objects)) != RT_OK) return rc;
