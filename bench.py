@@ -25,9 +25,14 @@ import numpy as np
 # One HIP stream per concurrent chain of launches: a frame uses five (trace/spawn + four shadow/light chains) and
 # several frames are in flight.  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (its
 # default, 4, is also what the environment of a GPU box usually holds); streams that share a queue run one after the
-# other, which serialises chains that are meant to overlap: a 1/8 shard of the frame then takes 2.2 ms instead of 1.6.
-# Four frames in flight are 20 streams, plus torch's and RCCL's own, so the bench asks for 24 (RT_HW_QUEUES overrides).
-os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_HW_QUEUES", "24")
+# other.  A whole frame's launches fill the chip on their own and 4 queues serve it as well as any number (1 % better
+# than 24, in fact).  The launches of a 1/N shard are N times shorter and only fill the chip when the chains of the
+# frames in flight really overlap: a 1/8 shard takes 2.2 ms with 4 queues and 1.6 ms with 24 (four frames in flight
+# are 20 streams, plus torch's and RCCL's own).  So a multi-GPU run asks for 24; RT_HW_QUEUES overrides either way.
+if os.environ.get("RT_HW_QUEUES"):
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ["RT_HW_QUEUES"]
+elif int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ["GPU_MAX_HW_QUEUES"] = "24"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
