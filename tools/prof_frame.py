@@ -1,4 +1,5 @@
-"""Renders a few frames of the benchmark scene with nothing else around them: the program to put under rocprofv3."""
+"""Renders a few frames of the benchmark scene with nothing else around them: the program to put under rocprofv3.
+SHARDS=n in the environment renders shard 0 of n instead of the whole frame."""
 import os
 import sys
 
@@ -12,7 +13,15 @@ w, h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (3840, 216
 s = scenes.synthetic_terrain_scene(w, h, cells=cells)
 ctx = ra.Context(0)
 ctx.upload(s)
+shards = int(os.environ.get("SHARDS", "1"))
+if shards > 1:
+    import torch
+    from raytracer_amd import dist as rd
+    buf = torch.zeros(rd.max_shard_slots(w, h, shards) * 3, dtype=torch.uint8, device="cuda:0")
 for _ in range(frames):
-    rgb, _, st = ctx.render()
+    if shards > 1:
+        st = ctx.render_shard(0, shards, buf.data_ptr())
+    else:
+        rgb, _, st = ctx.render()
 print(f"frames {frames} ms {st.ms_render:.3f} trace {st.ms_trace:.3f} shadow {st.ms_shadow:.3f} shade {st.ms_shade:.3f} rays {st.rays} nodes {st.nodes_visited} tris {st.tris_tested} wnodes {st.wave_nodes} wtris {st.wave_tris} long {st.long_trace} {st.long_shadow} max steps lane {st.max_lane_steps} wave {st.max_wave_steps}")
 ctx.close()
