@@ -158,10 +158,15 @@ inline Matrix from_forward(V3 vec) {                                            
     V3 up = cross(forward, right);
     return {0., 0., 0., right.x, right.y, right.z, up.x, up.y, up.z, -forward.x, -forward.y, -forward.z};
 }
+/* The sine and cosine of one angle come from ONE sincos() call: an optimising compiler turns a sin/cos pair of the same
+ * argument into that call anyway (gcc here, LLVM for the reference's release build), glibc's sincos and sin can differ
+ * in the last bit, and the device library's host code must arrive at the same matrix whatever its compiler does. */
 inline Matrix from_euler_xyz(double x, double y, double z) {                       // matrix.rs:60-72
-    Matrix a = {0., 0., 0., 1., 0., 0., 0., std::cos(x), -std::sin(x), 0., std::sin(x), std::cos(x)};
-    Matrix b = {0., 0., 0., std::cos(y), 0., std::sin(y), 0., 1., 0., -std::sin(y), 0., std::cos(y)};
-    Matrix c = {0., 0., 0., std::cos(z), -std::sin(z), 0., std::sin(z), std::cos(z), 0., 0., 0., 1.};
+    double sx, cx, sy, cy, sz, cz;
+    ::sincos(x, &sx, &cx); ::sincos(y, &sy, &cy); ::sincos(z, &sz, &cz);
+    Matrix a = {0., 0., 0., 1., 0., 0., 0., cx, -sx, 0., sx, cx};
+    Matrix b = {0., 0., 0., cy, 0., sy, 0., 1., 0., -sy, 0., cy};
+    Matrix c = {0., 0., 0., cz, -sz, 0., sz, cz, 0., 0., 0., 1.};
     return mat_mul(mat_mul(a, b), c);
 }
 

@@ -727,7 +727,12 @@ __device__ bool cast_closest_seg(const DScene& S, const Ray& ray, Closest& c, Vi
                     c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.n >= 2 ? mh.t1 : mh.t0; c.u = mh.u; c.v = mh.v; any = true;
                 }
             } else {
-                const double bound = any ? c.t : INFINITY;
+                double bound = any ? c.t : INFINITY;
+                // The K lanes of a group cut ONE interval into pieces, so they must agree on it: the best distance so
+                // far is the group's, not the lane's (each lane only knows what its own pieces of the earlier objects
+                // held; pieces of different intervals would leave gaps).  A hit at exactly that distance in this, later,
+                // object loses either way.
+                if (K > 1) for (uint32_t off = 1; off < K; off <<= 1) bound = fmin(bound, __shfl_xor(bound, (int)off));
                 Seg sg;
                 if (K > 1) sg = mesh_segment(S.meshes[o.payload], ray, bound, k, K);
                 else { sg.lo = -INFINITY; sg.hi = INFINITY; }

@@ -140,10 +140,15 @@ M4 m4mul(const M4& A, const M4& B) {
 }
 void camera_rotation(double pitch, double yaw, double rot[3][3]) {
     // from_euler_xyz(-pitch, yaw, 0) = a * b * c, matrix.rs:60-72
+    // Sine and cosine of an angle from ONE sincos() call: compilers merge a sin/cos pair of the same argument into it
+    // (or not), glibc's sincos and sin can differ in the last bit, and a ray direction that is one ulp off shows up as
+    // a grey level where a blend weight of exactly 1 lands the colour on an integer.
     const double x = -pitch, y = yaw, z = 0.;
-    M4 a = {{{1., 0., 0., 0.}, {0., std::cos(x), -std::sin(x), 0.}, {0., std::sin(x), std::cos(x), 0.}, {0., 0., 0., 1.}}};
-    M4 b = {{{std::cos(y), 0., std::sin(y), 0.}, {0., 1., 0., 0.}, {-std::sin(y), 0., std::cos(y), 0.}, {0., 0., 0., 1.}}};
-    M4 cc = {{{std::cos(z), -std::sin(z), 0., 0.}, {std::sin(z), std::cos(z), 0., 0.}, {0., 0., 1., 0.}, {0., 0., 0., 1.}}};
+    double sx, cx, sy, cy, sz, cz;
+    ::sincos(x, &sx, &cx); ::sincos(y, &sy, &cy); ::sincos(z, &sz, &cz);
+    M4 a = {{{1., 0., 0., 0.}, {0., cx, -sx, 0.}, {0., sx, cx, 0.}, {0., 0., 0., 1.}}};
+    M4 b = {{{cy, 0., sy, 0.}, {0., 1., 0., 0.}, {-sy, 0., cy, 0.}, {0., 0., 0., 1.}}};
+    M4 cc = {{{cz, -sz, 0., 0.}, {sz, cz, 0., 0.}, {0., 0., 1., 0.}, {0., 0., 0., 1.}}};
     M4 r = m4mul(m4mul(a, b), cc);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rot[i][j] = r.a[i][j];
 }

@@ -48,9 +48,13 @@ inline Matrix operator*(const Matrix& A, const Matrix& B) {
 }
 // matrix.rs:60-66
 inline void euler_matrices(double x, double y, double z, Matrix& a, Matrix& b, Matrix& c) {
-    a = Matrix(); a.m11 = std::cos(x); a.m12 = -std::sin(x); a.m21 = std::sin(x); a.m22 = std::cos(x);
-    b = Matrix(); b.m00 = std::cos(y); b.m02 = std::sin(y); b.m20 = -std::sin(y); b.m22 = std::cos(y);
-    c = Matrix(); c.m00 = std::cos(z); c.m01 = -std::sin(z); c.m10 = std::sin(z); c.m11 = std::cos(z);
+    // one sincos() per angle: what an optimising compiler makes of a sin/cos pair anyway, said outright so that the
+    // result does not depend on the compiler (glibc's sincos and sin can differ in the last bit)
+    double sx, cx, sy, cy, sz, cz;
+    ::sincos(x, &sx, &cx); ::sincos(y, &sy, &cy); ::sincos(z, &sz, &cz);
+    a = Matrix(); a.m11 = cx; a.m12 = -sx; a.m21 = sx; a.m22 = cx;
+    b = Matrix(); b.m00 = cy; b.m02 = sy; b.m20 = -sy; b.m22 = cy;
+    c = Matrix(); c.m00 = cz; c.m01 = -sz; c.m10 = sz; c.m11 = cz;
 }
 inline Matrix from_euler_xyz(double x, double y, double z) { Matrix a, b, c; euler_matrices(x, y, z, a, b, c); return a * b * c; }  // :69-72
 inline Matrix from_euler_zyx(double x, double y, double z) { Matrix a, b, c; euler_matrices(x, y, z, a, b, c); return c * b * a; }  // :75-78

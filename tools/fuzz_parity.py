@@ -1,0 +1,100 @@
+"""Random scenes, GPU frame against the CPU checker: colours, primary ids and ray counts must be identical.
+
+usage: fuzz_parity.py [n_scenes] [first_seed]
+Every scene draws its own mix of objects (0-40 spheres and boxes, so both the linear object list and the object tree
+occur; 0-2 planes; 0-2 height-field meshes, some see-through with ior 1, some refracting), materials, lights (suns
+with and without shadows, point lights with short and long reach), skybox kind, ray depth, camera and frame size
+(ragged sizes included).  A mismatch prints the seed and leaves the process with status 1.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle  # noqa: E402
+import raytracer_amd as ra  # noqa: E402
+from raytracer_amd import scenes  # noqa: E402
+
+
+def random_material(rng, allow_far=True):
+    kind = rng.integers(0, 6)
+    tex = ra.Texture.solid(tuple(int(x) for x in rng.integers(0, 256, 3)))
+    if kind == 0:
+        tex = ra.Texture.checkerboard(tuple(int(x) for x in rng.integers(0, 256, 3)), tuple(int(x) for x in rng.integers(0, 256, 3)))
+    refl = float(rng.choice([0., 0., 0.3, 0.8, 1.0]))
+    transp = float(rng.choice([0., 0., 0., 0.5, 0.9]))
+    ior = float(rng.choice([1.5, 1.5, 1.33, 1.0 if allow_far else 1.5, 2.4]))
+    emis = float(rng.choice([0., 0., 0., 0.5, 1.0]))
+    return scenes.sdl_material(tex, reflectiveness=refl, transparency=transp, ior=ior, emissivity=emis)
+
+
+def random_scene(seed):
+    rng = np.random.default_rng(seed)
+    vw, vh = int(rng.integers(17, 200)), int(rng.integers(9, 130))
+    s = ra.Scene()
+    s.set_camera(ra.Camera(vw=vw, vh=vh, origin=(float(rng.uniform(-2, 2)), float(rng.uniform(0.5, 4)), float(rng.uniform(6, 11))),
+                           yaw=float(rng.uniform(-0.3, 0.3)), pitch=float(rng.uniform(-0.5, 0.1)), fov=float(rng.uniform(40, 90))))
+    s.set_options(max_ray_depth=int(rng.integers(0, 6)), ambient=tuple(int(x) for x in rng.integers(0, 80, 3)))
+    sky = rng.integers(0, 3)
+    if sky == 0:
+        s.skybox_solid(tuple(int(x) for x in rng.integers(0, 256, 3)))
+    elif sky == 1:
+        s.skybox_normal()
+    else:
+        s.skybox_cubemap(scenes.procedural_cubemap(int(rng.integers(4, 24)), seed=seed))
+    for _ in range(int(rng.integers(0, 3))):
+        s.add_light(scenes.sdl_sun(tuple(float(x) for x in (rng.uniform(-1, 1), rng.uniform(-1, -0.2), rng.uniform(-1, 1))),
+                                   shadows=bool(rng.integers(0, 2)), intensity=float(rng.uniform(0.3, 1.2))))
+    for _ in range(int(rng.integers(0, 4))):
+        s.add_light(ra.Point(position=tuple(float(x) for x in (rng.uniform(-5, 5), rng.uniform(1, 7), rng.uniform(-5, 5))),
+                             intensity=float(rng.uniform(2, 20)), max_distance=float(rng.choice([3., 10., 50.])),
+                             color=tuple(int(x) for x in rng.integers(100, 256, 3))))
+    for _ in range(int(rng.integers(0, 3))):
+        cells = int(rng.integers(1, 20))
+        mesh = ra.Mesh.heightfield(cells, cells, cell=float(rng.uniform(0.3, 1.0)), amplitude=float(rng.uniform(0., 1.5)),
+                                   base_freq=float(rng.uniform(0.1, 0.5)), octaves=int(rng.integers(1, 4)), seed=int(rng.integers(0, 1000)),
+                                   material=random_material(rng))
+        scenes.sdl_mesh(mesh, position=(float(rng.uniform(-2, 2)), float(rng.uniform(-1.5, 1.0)), float(rng.uniform(-3, 2))),
+                        rotate_xyz=tuple(float(x) for x in rng.uniform(-0.4, 0.4, 3)) if rng.integers(0, 2) else None)
+        s.add(mesh)
+    for _ in range(int(rng.integers(0, 3))):
+        s.add(scenes.sdl_plane((0., float(rng.uniform(-3, -0.5)), 0.), normal=(float(rng.uniform(-0.2, 0.2)), 1., float(rng.uniform(-0.2, 0.2))),
+                               material=random_material(rng), uv_wrap=float(rng.choice([1., 2., 0.5]))))
+    n_small = int(rng.choice([0, 1, 3, 7, 8, 9, 20, 40]))
+    for _ in range(n_small):
+        pos = tuple(float(x) for x in (rng.uniform(-5, 5), rng.uniform(-1, 4), rng.uniform(-6, 3)))
+        if rng.integers(0, 3) == 0:
+            s.add(ra.Aabb(pos, tuple(float(x) for x in rng.uniform(0.1, 0.9, 3)), random_material(rng)))
+        else:
+            s.add(ra.Sphere(pos, float(rng.uniform(0.1, 1.2)), random_material(rng)))
+    return s, (vw, vh)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    bad = 0
+    with ra.Context(0) as ctx:
+        for seed in range(first, first + n):
+            s, (vw, vh) = random_scene(seed)
+            ctx.upload(s)
+            rgb, ids, st = ctx.render(ids=True)
+            o_rgb, o_ids, o_st, oc = oracle.render(s, 0)
+            same_rgb = np.array_equal(rgb, o_rgb)
+            same_ids = np.array_equal(ids, o_ids)
+            same_rays = (st.rays_primary, st.rays_reflect, st.rays_transmit, st.rays_shadow) == \
+                        (o_st.rays_primary, o_st.rays_reflect, o_st.rays_transmit, o_st.rays_shadow)
+            ok = same_rgb and same_ids and same_rays and oc.would_panic == 0
+            if not ok:
+                bad += 1
+                diff = int((rgb != o_rgb).any(axis=2).sum())
+                print(f"seed {seed}: {vw}x{vh} MISMATCH rgb {same_rgb} ({diff} pixels) ids {same_ids} rays {same_rays} panic {oc.would_panic}", flush=True)
+            elif (seed - first) % 10 == 0:
+                print(f"seed {seed}: {vw}x{vh} ok, {st.rays} rays", flush=True)
+    print(f"{n} scenes, {bad} mismatches", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
