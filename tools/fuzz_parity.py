@@ -1,6 +1,6 @@
 """Random scenes, GPU frame against the CPU checker: colours, primary ids and ray counts must be identical.
 
-usage: fuzz_parity.py [n_scenes] [first_seed]
+usage: fuzz_parity.py [n_scenes] [first_seed]      (FUZZ_RICH=1: image textures, larger meshes, more objects)
 Every scene draws its own mix of objects (0-40 spheres and boxes, so both the linear object list and the object tree
 occur; 0-2 planes; 0-2 height-field meshes, some see-through with ior 1, some refracting), materials, lights (suns
 with and without shadows, point lights with short and long reach), skybox kind, ray depth, camera and frame size
@@ -17,11 +17,13 @@ import raytracer_amd as ra  # noqa: E402
 from raytracer_amd import scenes  # noqa: E402
 
 
-def random_material(rng, allow_far=True):
+def random_material(rng, allow_far=True, rich=False):
     kind = rng.integers(0, 6)
     tex = ra.Texture.solid(tuple(int(x) for x in rng.integers(0, 256, 3)))
     if kind == 0:
         tex = ra.Texture.checkerboard(tuple(int(x) for x in rng.integers(0, 256, 3)), tuple(int(x) for x in rng.integers(0, 256, 3)))
+    elif kind == 1 and rich:
+        tex = ra.Texture.image(rng.integers(0, 256, (int(rng.integers(1, 40)), int(rng.integers(1, 40)), 3), dtype=np.uint8))
     refl = float(rng.choice([0., 0., 0.3, 0.8, 1.0]))
     transp = float(rng.choice([0., 0., 0., 0.5, 0.9]))
     ior = float(rng.choice([1.5, 1.5, 1.33, 1.0 if allow_far else 1.5, 2.4]))
@@ -29,7 +31,9 @@ def random_material(rng, allow_far=True):
     return scenes.sdl_material(tex, reflectiveness=refl, transparency=transp, ior=ior, emissivity=emis)
 
 
-def random_scene(seed):
+def random_scene(seed, rich=False):
+    """rich: image textures on planes, boxes and meshes (not on spheres, whose texture coordinates go through
+    atan2/asin and may differ in the last bit between the two libms), larger meshes, more objects"""
     rng = np.random.default_rng(seed)
     vw, vh = int(rng.integers(17, 200)), int(rng.integers(9, 130))
     s = ra.Scene()
@@ -51,21 +55,21 @@ def random_scene(seed):
                              intensity=float(rng.uniform(2, 20)), max_distance=float(rng.choice([3., 10., 50.])),
                              color=tuple(int(x) for x in rng.integers(100, 256, 3))))
     for _ in range(int(rng.integers(0, 3))):
-        cells = int(rng.integers(1, 20))
+        cells = int(rng.integers(1, 60 if rich else 20))
         mesh = ra.Mesh.heightfield(cells, cells, cell=float(rng.uniform(0.3, 1.0)), amplitude=float(rng.uniform(0., 1.5)),
                                    base_freq=float(rng.uniform(0.1, 0.5)), octaves=int(rng.integers(1, 4)), seed=int(rng.integers(0, 1000)),
-                                   material=random_material(rng))
+                                   material=random_material(rng, rich=rich))
         scenes.sdl_mesh(mesh, position=(float(rng.uniform(-2, 2)), float(rng.uniform(-1.5, 1.0)), float(rng.uniform(-3, 2))),
                         rotate_xyz=tuple(float(x) for x in rng.uniform(-0.4, 0.4, 3)) if rng.integers(0, 2) else None)
         s.add(mesh)
     for _ in range(int(rng.integers(0, 3))):
         s.add(scenes.sdl_plane((0., float(rng.uniform(-3, -0.5)), 0.), normal=(float(rng.uniform(-0.2, 0.2)), 1., float(rng.uniform(-0.2, 0.2))),
-                               material=random_material(rng), uv_wrap=float(rng.choice([1., 2., 0.5]))))
-    n_small = int(rng.choice([0, 1, 3, 7, 8, 9, 20, 40]))
+                               material=random_material(rng, rich=rich), uv_wrap=float(rng.choice([1., 2., 0.5]))))
+    n_small = int(rng.choice([0, 1, 3, 7, 8, 9, 20, 40, 150] if rich else [0, 1, 3, 7, 8, 9, 20, 40]))
     for _ in range(n_small):
         pos = tuple(float(x) for x in (rng.uniform(-5, 5), rng.uniform(-1, 4), rng.uniform(-6, 3)))
         if rng.integers(0, 3) == 0:
-            s.add(ra.Aabb(pos, tuple(float(x) for x in rng.uniform(0.1, 0.9, 3)), random_material(rng)))
+            s.add(ra.Aabb(pos, tuple(float(x) for x in rng.uniform(0.1, 0.9, 3)), random_material(rng, rich=rich)))
         else:
             s.add(ra.Sphere(pos, float(rng.uniform(0.1, 1.2)), random_material(rng)))
     return s, (vw, vh)
@@ -74,10 +78,11 @@ def random_scene(seed):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    rich = bool(int(os.environ.get("FUZZ_RICH", "0")))
     bad = 0
     with ra.Context(0) as ctx:
         for seed in range(first, first + n):
-            s, (vw, vh) = random_scene(seed)
+            s, (vw, vh) = random_scene(seed, rich)
             ctx.upload(s)
             rgb, ids, st = ctx.render(ids=True)
             o_rgb, o_ids, o_st, oc = oracle.render(s, 0)
