@@ -1,6 +1,7 @@
 """Random scenes, GPU frame against the CPU checker: colours, primary ids and ray counts must be identical.
 
-usage: fuzz_parity.py [n_scenes] [first_seed]      (FUZZ_RICH=1: image textures, larger meshes, more objects)
+usage: fuzz_parity.py [n_scenes] [first_seed]      (FUZZ_RICH=1: image textures, larger meshes, more objects;
+                                                    FUZZ_SHARDS=1: every frame also rendered as 2-9 shards and reassembled)
 Every scene draws its own mix of objects (0-40 spheres and boxes, so both the linear object list and the object tree
 occur; 0-2 planes; 0-2 height-field meshes, some see-through with ior 1, some refracting), materials, lights (suns
 with and without shadows, point lights with short and long reach), skybox kind, ray depth, camera and frame size
@@ -79,12 +80,27 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     rich = bool(int(os.environ.get("FUZZ_RICH", "0")))
+    shards = bool(int(os.environ.get("FUZZ_SHARDS", "0")))
     bad = 0
     with ra.Context(0) as ctx:
         for seed in range(first, first + n):
             s, (vw, vh) = random_scene(seed, rich)
             ctx.upload(s)
             rgb, ids, st = ctx.render(ids=True)
+            if shards:
+                # the same frame again as 2-9 shards, gathered and de-tiled: must be the frame just rendered
+                import torch
+                from raytracer_amd import dist as rd
+                n_sh = 2 + seed % 8
+                slots = rd.max_shard_slots(vw, vh, n_sh)
+                gathered = torch.zeros(n_sh * slots * 3, dtype=torch.uint8, device="cuda")
+                frame = torch.zeros(vh * vw * 3, dtype=torch.uint8, device="cuda")
+                sh_rays = sum(ctx.render_shard(k, n_sh, gathered.data_ptr() + k * slots * 3).rays for k in range(n_sh))
+                torch.cuda.synchronize()
+                ctx.detile(gathered.data_ptr(), n_sh, slots, 3, frame.data_ptr())
+                if not (np.array_equal(frame.cpu().numpy().reshape(vh, vw, 3), rgb) and sh_rays == st.rays):
+                    bad += 1
+                    print(f"seed {seed}: {vw}x{vh} SHARD MISMATCH with {n_sh} shards", flush=True)
             o_rgb, o_ids, o_st, oc = oracle.render(s, 0)
             same_rgb = np.array_equal(rgb, o_rgb)
             same_ids = np.array_equal(ids, o_ids)
