@@ -60,7 +60,8 @@ def test_against_oracle(gpu_ctx, builder, args):
     rgb, ids, st = gpu_ctx.render(ids=True)
     o_rgb, o_ids, o_st, oc = oracle.render(s, 0)
     assert oc.would_panic == 0
-    assert_parity(rgb, ids, o_rgb, o_ids)
+    assert_parity(rgb, ids, o_rgb, o_ids, exact_floor=1.0)     # none of these scenes puts an image on a sphere
+    assert np.array_equal(ids, o_ids)
     assert ray_counts(st) == ray_counts(o_st)
     assert list(st.rays_per_level) == list(o_st.rays_per_level)
 
@@ -355,7 +356,7 @@ def test_long_ray_lists_keep_parity(builder, args, monkeypatch):
         rgb, ids, st = ctx.render(ids=True)
     o_rgb, o_ids, o_st, oc = oracle.render(s, 0)
     assert st.long_trace > 0 and st.long_shadow > 0
-    assert_parity(rgb, ids, o_rgb, o_ids)
+    assert_parity(rgb, ids, o_rgb, o_ids, exact_floor=1.0)
     assert ray_counts(st) == ray_counts(o_st)
 
 
