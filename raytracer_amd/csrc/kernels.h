@@ -25,8 +25,12 @@
 // (row-major inside the supertile); tiles of an edge supertile that lie outside the image are all padding.
 // Neighbouring tiles share most of the BVH nodes their rays touch: handing a GPU whole 64 x 64 pixel blocks instead
 // of every n-th tile keeps those nodes in its L2.
+// Row r of supertiles is rotated left by r * row_rot columns before the numbering, chosen so that the column phase a
+// shard owns moves by a step coprime to n_shards from one row to the next: over n_shards rows every shard gets every
+// phase once (a Latin square) instead of the two phases that 60 supertiles per row and 8 shards would give, and what
+// is expensive in the picture (an object, the horizon) is spread over the shards.
 struct ShardMap {
-    uint32_t shard, n_shards, supers_x, n_supers, super_shift;
+    uint32_t shard, n_shards, supers_x, n_supers, super_shift, row_rot;
     uint32_t row_major_out;                       // 1: write the frame row-major; 0: compact slot order
 };
 
@@ -35,8 +39,10 @@ DEV bool slot_pixel(const ShardMap& m, int32_t vw, int32_t vh, uint32_t slot, in
     const uint32_t k = slot >> (8u + 2u * sh), t = (slot >> 8) & ((1u << (2u * sh)) - 1u), j = slot & 255u;
     const uint64_t sid = (uint64_t)k * m.n_shards + m.shard;
     if (sid >= m.n_supers) return false;
-    const uint32_t tx = ((uint32_t)(sid % m.supers_x) << sh) + (t & ((1u << sh) - 1u));
-    const uint32_t ty = ((uint32_t)(sid / m.supers_x) << sh) + (t >> sh);
+    const uint32_t sy = (uint32_t)(sid / m.supers_x);
+    const uint32_t sx = (uint32_t)((sid % m.supers_x + (uint64_t)sy * m.row_rot) % m.supers_x);
+    const uint32_t tx = (sx << sh) + (t & ((1u << sh) - 1u));
+    const uint32_t ty = (sy << sh) + (t >> sh);
     // the 64 slots of one wave cover an 8x8 pixel block (a compact ray packet); four blocks make the tile
     const uint32_t sub = j >> 6, w = j & 63u;
     x = (int32_t)(tx * 16u + (sub & 1u) * 8u + (w & 7u));

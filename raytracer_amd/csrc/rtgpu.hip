@@ -432,6 +432,17 @@ uint32_t super_shift() {
     return v;
 }
 
+// The rotation per row of supertiles (see ShardMap): with it the owner of column x in row y is (x + y * g) mod n for a
+// step g near 0.38 n that is coprime to n.
+uint32_t shard_row_rotation(uint32_t supers_x, uint32_t n_shards) {
+    if (n_shards <= 1 || supers_x == 0) return 0;
+    auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+    uint32_t g = std::max<uint32_t>(1, (uint32_t)std::lround(0.382 * n_shards));
+    while (gcd(g, n_shards) != 1) g++;
+    // unrotated, the step is supers_x mod n; a rotation by R columns makes it (supers_x - R) mod n
+    return (supers_x % n_shards + n_shards - g % n_shards) % n_shards;
+}
+
 ShardMap make_map(int32_t vw, int32_t vh, uint32_t shard, uint32_t n_shards, uint32_t row_major) {
     ShardMap m;
     m.shard = shard; m.n_shards = n_shards;
@@ -439,6 +450,7 @@ ShardMap make_map(int32_t vw, int32_t vh, uint32_t shard, uint32_t n_shards, uin
     const int32_t side = RT_TILE_W << m.super_shift;
     m.supers_x = (uint32_t)((vw + side - 1) / side);
     m.n_supers = m.supers_x * (uint32_t)((vh + side - 1) / side);
+    m.row_rot = shard_row_rotation(m.supers_x, n_shards);
     m.row_major_out = row_major;
     return m;
 }
@@ -447,7 +459,8 @@ uint64_t valid_pixels(const ShardMap& m, int32_t vw, int32_t vh) {
     uint64_t n = 0;
     const int32_t side = RT_TILE_W << m.super_shift;
     for (uint64_t sid = m.shard; sid < m.n_supers; sid += m.n_shards) {
-        const int32_t sx = (int32_t)(sid % m.supers_x), sy = (int32_t)(sid / m.supers_x);
+        const int32_t sy = (int32_t)(sid / m.supers_x);
+        const int32_t sx = (int32_t)((sid % m.supers_x + (uint64_t)sy * m.row_rot) % m.supers_x);
         n += (uint64_t)std::min<int32_t>(side, vw - sx * side) * (uint64_t)std::min<int32_t>(side, vh - sy * side);
     }
     return n;

@@ -23,6 +23,17 @@ def n_supertiles(vw, vh):
     return ((vw + side - 1) // side) * ((vh + side - 1) // side)
 
 
+def row_rotation(supers_x, n_shards):
+    """columns by which row r of supertiles is rotated, per row -- mirrors the library's shard_row_rotation"""
+    import math
+    if n_shards <= 1 or supers_x == 0:
+        return 0
+    g = max(1, int(math.floor(0.382 * n_shards + 0.5)))
+    while math.gcd(g, n_shards) != 1:
+        g += 1
+    return (supers_x % n_shards + n_shards - g % n_shards) % n_shards
+
+
 def shard_slots(vw, vh, shard, n_shards):
     """number of pixel slots (whole supertiles) of one shard -- mirrors rt_shard_pixels"""
     t = n_supertiles(vw, vh)
@@ -44,8 +55,12 @@ def shard_pixel_indices(vw, vh, shard, n_shards):
     k, t, j = slot // per_super, (slot >> 8) % (S * S), slot & 255
     sid = k * n_shards + shard
     supers_x = (vw + TILE * S - 1) // (TILE * S)
-    tx = (sid % supers_x) * S + t % S
-    ty = (sid // supers_x) * S + t // S
+    # each row of supertiles is rotated so that the column phase a shard owns moves by a step coprime to n_shards
+    # from row to row (the library's shard_row_rotation)
+    sy = sid // supers_x
+    sx = (sid % supers_x + sy * row_rotation(supers_x, n_shards)) % supers_x
+    tx = sx * S + t % S
+    ty = sy * S + t // S
     # the 64 slots of one wave cover an 8x8 pixel block; four blocks make the 16x16 tile
     sub, w = j >> 6, j & 63
     x = tx * TILE + (sub & 1) * 8 + (w & 7)

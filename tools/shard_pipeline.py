@@ -12,6 +12,7 @@ import raytracer_amd as ra  # noqa: E402
 from raytracer_amd import dist as rd, scenes  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+shard = int(os.environ.get("SHARD", "0"))     # which of the n shards
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 s = scenes.synthetic_terrain_scene(3840, 2160)
 for depth in [int(x) for x in os.environ.get("DEPTHS", "1,2,3,4").split(",")]:
@@ -20,9 +21,11 @@ for depth in [int(x) for x in os.environ.get("DEPTHS", "1,2,3,4").split(",")]:
         c.upload(s)
     bufs = [torch.zeros(rd.max_shard_slots(3840, 2160, n) * 3, dtype=torch.uint8, device="cuda:0") for _ in range(depth)]
 
+    last = [None]
+
     def work(k, count):
         for _ in range(count):
-            ctxs[k].render_shard(0, n, bufs[k].data_ptr())
+            last[0] = ctxs[k].render_shard(shard, n, bufs[k].data_ptr())
 
     for k in range(depth):
         work(k, 2)
@@ -35,6 +38,6 @@ for depth in [int(x) for x in os.environ.get("DEPTHS", "1,2,3,4").split(",")]:
         t.join()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) * 1e3 / (frames * depth)
-    print(f"shard 0 of {n}, {depth} in flight: {dt:.3f} ms per frame", flush=True)
+    print(f"shard {shard} of {n}, {depth} in flight: {dt:.3f} ms per frame, {last[0].rays} rays", flush=True)
     for c in ctxs:
         c.close()
