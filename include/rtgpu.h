@@ -232,9 +232,12 @@ int rt_render(rt_ctx* ctx, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* st
  * scene.rs:239-242).  The image is cut into supertiles of S x S tiles of
  * RT_TILE_W x RT_TILE_H pixels, S = rt_supertile() (4 unless the environment
  * variable RTGPU_SUPER_SHIFT = log2 S says otherwise; one value per process).
- * Supertiles are numbered row-major; shard s of n owns supertiles s, s+n,
- * s+2n, ...  rt_shard_pixels returns the number of pixel slots (whole
- * supertiles, edges padded) shard s produces. */
+ * Supertiles are numbered row by row, each row rotated by a few columns
+ * against the one above (so that the columns a shard owns differ from row to
+ * row); shard s of n owns supertiles s, s+n, s+2n, ... of that numbering.
+ * Which pixel a slot holds is the library's business: rt_detile puts gathered
+ * shard buffers back into a row-major frame.  rt_shard_pixels returns the
+ * number of pixel slots (whole supertiles, edges padded) shard s produces. */
 #define RT_TILE_W 16
 #define RT_TILE_H 16
 int64_t rt_shard_pixels(int32_t vw, int32_t vh, uint32_t shard, uint32_t n_shards);
