@@ -73,6 +73,33 @@ def test_shard_map_partitions_the_image():
             assert (seen == 1).all()                        # every pixel in exactly one shard
 
 
+def test_shard_rows_cycle_through_every_column_phase():
+    """the numbering rotates each row of supertiles so that the owner of column x in row y is (x + g*y) mod n with
+    g coprime to n: in n consecutive rows a shard owns every column phase once (4K frame, 8 shards: a shard no
+    longer sits on the same columns in every other row)"""
+    import math
+    from raytracer_amd import dist as rd
+    side = rd.TILE * rd.supertile()
+    for vw, vh, n in [(3840, 2160, 8), (3840, 2160, 4), (1920, 1080, 2), (2560, 1440, 3), (7680, 4320, 8), (1237, 911, 5)]:
+        supers_x, supers_y = -(-vw // side), -(-vh // side)
+        owner = np.full((supers_y, supers_x), -1)
+        for s in range(n):
+            idx = rd.shard_pixel_indices(vw, vh, s, n)
+            idx = idx[idx >= 0]
+            owner[(idx // vw) // side, (idx % vw) // side] = s
+        assert (owner >= 0).all()
+        if supers_x <= (n - 1) * (n - 1) + 1 or supers_y < n:
+            continue
+        # right of the wrap-around seam of the rotated rows (it moves right by fewer than n columns a row), the owner
+        # moves by one per column and by g per row
+        x0 = supers_x - 1
+        step = (owner[1, x0] - owner[0, x0]) % n
+        assert math.gcd(int(step), n) == 1
+        assert (owner[0, x0] - owner[0, x0 - 1]) % n == 1
+        phases = {int(owner[y, x0]) for y in range(n)}
+        assert phases == set(range(n))
+
+
 class _OracleCtx:
     """Stands in for a GPU context on the CPU: the shard comes from the oracle, the de-tile from its host statement.
     Frame f is rendered with the sphere row shifted by f, so frames differ and their order can be checked."""
