@@ -10,7 +10,7 @@ One step = one frame: every rank renders its interleaved 16x16 tiles (rt_render_
 gathered to rank 0 (RCCL) and scattered into the row-major frame (rt_detile).  The scene is resident in HBM before the
 timed region; the frame stays in HBM.  A ray is one Scene::cast_ray_once call of the reference.
 
-The K timed frames are a sequence (the reference's --sequence workload): --frames-in-flight F (default 4) of them are
+The K timed frames are a sequence (the reference's --sequence workload): --frames-in-flight F (default 4; 8 when the frame is sharded) of them are
 in flight per GPU, each complete and delivered in order; F = 1 renders them strictly one after the other.  The line
 also carries the one-frame-at-a-time figure (`ms_per_frame_alone`).
 """
@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--cells", type=int, default=708)
     ap.add_argument("--lights", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--frames-in-flight", type=int, default=4)
+    ap.add_argument("--frames-in-flight", type=int, default=None)
     args = ap.parse_args()
 
     import torch
@@ -125,6 +125,13 @@ def main():
         t_upload[0] = time.perf_counter() - t0
         return c
 
+    if args.frames_in_flight is None:
+        # One GPU, whole frame: 4 frames in flight, each with four shadow/light chains of its own.  A shard's launches are
+        # short, and what fills the chip then is more frames rather than more chains per frame: 8 frames with one
+        # shadow/light chain each (16 streams) render a 1/8 shard 2 % faster, halves and quarters equally fast.
+        args.frames_in_flight = 4 if world == 1 else 8
+        if world > 1:
+            os.environ.setdefault("RTGPU_SIDE_STREAMS", "1")
     depth = max(1, args.frames_in_flight)
     pipe = rd.FramePipeline(make_context, rank, world, device, depth=depth)
     t_upload = t_upload[0]
