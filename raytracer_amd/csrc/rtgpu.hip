@@ -80,7 +80,7 @@ struct rt_ctx {
     uint32_t long_below = 300000u;                  // ... applied to launches of fewer rays than this
     int count_visits = 0;                             // RTGPU_COUNT_VISITS: bit 0 k_trace, bit 1 k_shadow, bit 2 k_shade instrumented
     uint32_t n_lights = 0;
-    hipEvent_t ev[4];
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scene_bytes = 0, work_bytes = 0;
     double ms_upload = 0.;
 };
@@ -184,6 +184,8 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
     if (m.n_tris == 0 || !m.tri_pos || !m.tri_nrm || !m.verts) return fail(c, RT_ERR_INVALID, "mesh without triangles");
     if (m.n_prims == 0 || !m.prim_indices) return fail(c, RT_ERR_INVALID, "mesh without leaf primitive list");
     if (m.n_prims >= 0x7FFFFFFFu) return fail(c, RT_ERR_UNSUPPORTED, "mesh too large");
+    if (m.n_normals != 0 && !m.normals) return fail(c, RT_ERR_INVALID, "mesh: normals is NULL but n_normals is not 0");
+    if (m.n_texcoords != 0 && !m.texcoords) return fail(c, RT_ERR_INVALID, "mesh: texcoords is NULL but n_texcoords is not 0");
     {
         std::atomic<int> bad{0};   // 1 vertex, 2 normal, 3 texcoord
         parallel_for((size_t)3 * m.n_tris, [&](size_t a, size_t b) {
@@ -499,7 +501,7 @@ int ensure_level_counts(rt_ctx* c, size_t n) {
 // The shadow casts of a level need only that level's hits, and the next level needs only the spawned rays, so the
 // two chains run side by side: the long tail of a shadow launch (a few rays that skim the whole mesh) overlaps with
 // the trace of the deeper levels instead of idling the chip.  k_resolve waits for every k_light.
-int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st) {
+int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st) {
     if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
     HIP_TRY(c, hipSetDevice(c->device));
     const int64_t n0s = rt_shard_pixels(c->vw, c->vh, shard, n_shards);
@@ -610,10 +612,7 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
         HIP_TRY(c, hipStreamSynchronize(s));
         HIP_TRY(c, hipGetLastError());
         const unsigned long long spawned = c->h_lcounts[depth].next_count;
-        if (spawned > next_cap) {
-            for (auto side_s : c->side) if (side_s) (void)hipStreamSynchronize(side_s);
-            return fail(c, RT_ERR_DEVICE, "wavefront level overflow");
-        }
+        if (spawned > next_cap) return fail(c, RT_ERR_DEVICE, "wavefront level overflow");
         if (spawned > 0 && can_spawn) {
             counts.push_back((uint32_t)spawned);
             if (depth + 1 < 8) stats.rays_per_level[depth + 1] = spawned;
@@ -664,6 +663,21 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
     return RT_OK;
 }
 
+// Every error exit of a frame passes through here: kernels of earlier levels may still be writing the level buffers,
+// the occlusion bytes or the caller's output buffer on the main and side streams, and the caller may free that
+// buffer as soon as it sees the error code.
+int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st) {
+    const int rc = render_frame_impl(c, shard, n_shards, row_major, d_rgb, d_ids, st);
+    if (rc != RT_OK) {
+        const std::string keep = c->err;
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        for (auto side_s : c->side) if (side_s) (void)hipStreamSynchronize(side_s);
+        (void)hipGetLastError();
+        c->err = keep;
+    }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -700,7 +714,8 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         if (const char* b = std::getenv("RTGPU_PACKET_DEPTH")) c->packet_depth = (uint32_t)std::strtoul(b, nullptr, 10);
         if (const char* b = std::getenv("RTGPU_BUDGET_BELOW")) c->long_below = (uint32_t)std::strtoul(b, nullptr, 10);
     }
-    auto bail = [&](const char* what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); delete c; return RT_ERR_DEVICE; };
+    for (auto& ev : c->ev) ev = nullptr;
+    auto bail = [&](const char* what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); rt_ctx_destroy(c); return RT_ERR_DEVICE; };
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
     // (all streams at the default priority: mixed priorities hung the frame on this ROCm)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
@@ -766,6 +781,17 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     if (d->camera.vw <= 0 || d->camera.vh <= 0) return fail(c, RT_ERR_INVALID, "camera: vw and vh must be positive");
     if ((uint64_t)d->camera.vw * (uint64_t)d->camera.vh >= 0x7FFFFFFFull) return fail(c, RT_ERR_UNSUPPORTED, "frame larger than 2^31 pixels");
     if (d->options.max_ray_depth > 7) return fail(c, RT_ERR_UNSUPPORTED, "max_ray_depth above 7 is not supported");
+    {
+        // every array the description names is dereferenced below: a count without an array is refused here
+        const struct { const void* p; uint32_t n; const char* what; } arrays[] = {
+            {d->objects, d->n_objects, "objects"}, {d->spheres, d->n_spheres, "spheres"}, {d->planes, d->n_planes, "planes"},
+            {d->boxes, d->n_boxes, "boxes"}, {d->meshes, d->n_meshes, "meshes"}, {d->materials, d->n_materials, "materials"},
+            {d->textures, d->n_textures, "textures"}, {d->lights, d->n_lights, "lights"}};
+        for (const auto& a : arrays)
+            if (a.n != 0 && !a.p) return fail(c, RT_ERR_INVALID, std::string("scene: ") + a.what + " is NULL but its count is not 0");
+    }
+    // the shadow kernels take the light from the grid's y index
+    if (d->n_lights > 65535u) return fail(c, RT_ERR_UNSUPPORTED, "more than 65535 lights");
     for (uint32_t i = 0; i < d->n_lights; i++) {
         if (d->lights[i].kind == RT_LIGHT_AREA) return fail(c, RT_ERR_UNSUPPORTED, "area lights draw from an unseeded RNG (lighting/area.rs:121) and are not rendered on the device");
         if (d->lights[i].kind > RT_LIGHT_AREA) return fail(c, RT_ERR_INVALID, "unknown light kind");
