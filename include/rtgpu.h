@@ -265,6 +265,16 @@ int rt_detile(rt_ctx* ctx, const void* d_gathered, uint32_t n_shards,
 int rt_cast_rays(rt_ctx* ctx, uint32_t n, const double* origins, const double* dirs,
                  rt_ray_hit* hits_out);
 
+/* rt_cast_rays for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments and results as
+ * rt_cast_rays, but the rays and hit records are staged in a fixed array that lives in the library's device image
+ * (RT_CAST_NOALLOC_MAX * 152 bytes, about 10 MB, held on every GPU the library runs on until the process ends), so
+ * the call makes no hipMalloc / hipFree.  n above RT_CAST_NOALLOC_MAX is refused with RT_ERR_INVALID.  All contexts
+ * on one GPU share that array: calls that overlap in time on one GPU race with each other. */
+#define RT_CAST_NOALLOC_MAX 65536u
+int rt_cast_rays_noalloc(rt_ctx* ctx, uint32_t n, const double* origins, const double* dirs,
+                         rt_ray_hit* hits_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,7 +77,7 @@ _host = None
 
 GPU_SYMBOLS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload", "rt_render",
-    "rt_shard_pixels", "rt_supertile", "rt_render_shard", "rt_detile", "rt_cast_rays",
+    "rt_shard_pixels", "rt_supertile", "rt_render_shard", "rt_detile", "rt_cast_rays", "rt_cast_rays_noalloc",
 ]
 
 
@@ -105,6 +105,8 @@ def gpu():
         L.rt_detile.restype = C.c_int
         L.rt_cast_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_cast_rays.restype = C.c_int
+        L.rt_cast_rays_noalloc.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_cast_rays_noalloc.restype = C.c_int
         _gpu = L
     return _gpu
 

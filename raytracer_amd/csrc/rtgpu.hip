@@ -16,6 +16,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -43,8 +44,40 @@ enum { LW_T0, LW_T1, LW_P, LW_S0, LW_S1, LW_L0, LW_L1 };
 
 }  // namespace
 
+// ---- rt_cast_rays_noalloc: staging for the probe rays and their hit records in a file-scope device array instead of
+// per-call hipMalloc.  Every GPU the library runs on holds its own copy of the array (at its own address) until the
+// process ends.  In host code the array's NAME is only a handle for hipGetSymbolAddress -- it is not a device
+// address -- so the address is looked up once per device (rt_ctx_create, with that device current) and everything
+// below works with the looked-up pointer.
+#define RT_NOALLOC_ORIGINS_OFF 0u
+#define RT_NOALLOC_DIRS_OFF    ((size_t)RT_CAST_NOALLOC_MAX * 24u)
+#define RT_NOALLOC_HITS_OFF    ((size_t)RT_CAST_NOALLOC_MAX * 48u)
+#define RT_NOALLOC_BYTES       ((size_t)RT_CAST_NOALLOC_MAX * (48u + sizeof(rt_ray_hit)))
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
+namespace {
+#define RT_MAX_DEVICES 64
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[RT_MAX_DEVICES] = {};   // device address of `scratch` on each device, once looked up
+
+// the calling thread's current device must be `device`
+hipError_t scratch_address(int device, void** out) {
+    *out = nullptr;
+    if (device < 0 || device >= RT_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+}  // namespace
+
 struct rt_ctx {
     int device = 0;
+    void* scratch = nullptr;       // this device's copy of the file-scope staging array (rt_cast_rays_noalloc)
     hipStream_t stream = nullptr;
     std::string err;
     std::vector<void*> scene_allocs;
@@ -717,6 +750,7 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     for (auto& ev : c->ev) ev = nullptr;
     auto bail = [&](const char* what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); rt_ctx_destroy(c); return RT_ERR_DEVICE; };
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = scratch_address(device_id, &c->scratch)) != hipSuccess) return bail("hipGetSymbolAddress", e);
     // (all streams at the default priority: mixed priorities hung the frame on this ROCm)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if (const char* b = std::getenv("RTGPU_SIDE_STREAMS")) c->n_side = std::min<uint32_t>(RT_SIDE_STREAMS, std::max<uint32_t>(1, (uint32_t)std::strtoul(b, nullptr, 10)));
@@ -1086,6 +1120,34 @@ int rt_cast_rays(rt_ctx* c, uint32_t n, const double* origins, const double* dir
     if (d_d) (void)hipFree(d_d);
     if (d_h) (void)hipFree(d_h);
     return rc;
+}
+
+// rt_cast_rays without any allocation: the rays and their hit records are staged in this device's copy of the
+// file-scope array.  All calls on one GPU share that array.
+int rt_cast_rays_noalloc(rt_ctx* c, uint32_t n, const double* origins, const double* dirs, rt_ray_hit* hits_out) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
+    if (n == 0) return RT_OK;
+    if (!origins || !dirs || !hits_out) return fail(c, RT_ERR_INVALID, "rt_cast_rays_noalloc: NULL argument");
+    if (n > RT_CAST_NOALLOC_MAX)
+        return fail(c, RT_ERR_INVALID, "rt_cast_rays_noalloc: " + std::to_string(n) + " rays exceed the limit of " + std::to_string(RT_CAST_NOALLOC_MAX) +
+                                           " per call (RT_CAST_NOALLOC_MAX); split the batch or use rt_cast_rays");
+    if (!c->scratch) return fail(c, RT_ERR_DEVICE, "rt_cast_rays_noalloc: the staging array's address is unknown");
+    static_assert(sizeof(DProbeHit) == sizeof(rt_ray_hit), "probe record layout");
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned char* base = static_cast<unsigned char*>(c->scratch);
+    double* d_o = reinterpret_cast<double*>(base + RT_NOALLOC_ORIGINS_OFF);
+    double* d_d = reinterpret_cast<double*>(base + RT_NOALLOC_DIRS_OFF);
+    DProbeHit* d_h = reinterpret_cast<DProbeHit*>(base + RT_NOALLOC_HITS_OFF);
+    // nothing in the array has to start at zero: the first n rays are overwritten here and the kernel writes every
+    // field of the first n hit records, which are the only ones copied out
+    HIP_TRY(c, hipMemcpyAsync(d_o, origins, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_d, dirs, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_probe, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->dscene, d_o, d_d, d_h, n);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(hits_out, d_h, (size_t)n * sizeof(DProbeHit), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
 }
 
 }  // extern "C"
