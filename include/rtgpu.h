@@ -191,6 +191,16 @@ typedef struct rt_stats {
     /* instrumented contexts only: bytes of BVH data (node and triangle records, at their real sizes) the walks of
      * the last frame fetched; a packet's shared fetch counts once */
     uint64_t bytes_fetched;
+    /* The budget-free shadow packet kernel (the large launches of a frame, where most of its time goes): its own launch
+     * durations summed over the levels that used it, their number, and (instrumented contexts) the BVH bytes those
+     * levels' walks fetched. */
+    double   ms_shadow_main;
+    uint64_t bytes_fetched_main;
+    uint32_t launches_shadow_main;
+    /* 1: the frame was queued without reading the level sizes back (they were taken from the context's previous frame) */
+    uint32_t speculative;
+    /* frames of this context that were rendered twice because a level outgrew the room its predecessor suggested */
+    uint64_t respeculated;
 } rt_stats;
 
 /* result of one probe ray (rt_cast_rays): the fields of object/mod.rs:18-36
@@ -258,6 +268,21 @@ int rt_render_shard(rt_ctx* ctx, uint32_t shard, uint32_t n_shards,
  * DEVICE memory.  elem_bytes is 3 (rgb) or 8 (id pairs). */
 int rt_detile(rt_ctx* ctx, const void* d_gathered, uint32_t n_shards,
               int64_t slots_per_shard, uint32_t elem_bytes, void* d_image);
+
+/* The sequence workload (sdl/src/main.rs:70-95 renders frame after frame) on a GPU that owns one shard of every
+ * frame: renders shard `shard` of n_frames frames that differ in their camera only -- a camera path through the
+ * uploaded scene -- as ONE set of launches, so that the launches of a small shard stay large enough to fill the
+ * chip.  cameras[f].vw/vh must equal the uploaded scene's.  Frame f's compact shard (layout as rt_render_shard)
+ * starts at slot f * frame_stride of d_rgb / d_ids; frame_stride >= rt_shard_pixels() (ranks pad to the largest
+ * shard, shard 0's, so that gathered buffers line up: rt_detile_frames).  1 <= n_frames <= RT_BATCH_MAX. */
+#define RT_BATCH_MAX 64u
+int rt_render_shard_batch(rt_ctx* ctx, uint32_t shard, uint32_t n_shards, uint32_t n_frames, const rt_camera* cameras,
+                          int64_t frame_stride, void* d_rgb, void* d_ids, rt_stats* stats_out);
+
+/* rt_detile for gathered batches: d_gathered is [shard][frame][slot] (each run padded to slots_per_shard slots),
+ * d_images receives n_frames row-major images one after the other. */
+int rt_detile_frames(rt_ctx* ctx, const void* d_gathered, uint32_t n_shards, uint32_t n_frames,
+                     int64_t slots_per_shard, uint32_t elem_bytes, void* d_images);
 
 /* Probe: casts n arbitrary rays through the uploaded scene with the semantics
  * of Scene::cast_ray_once (scene.rs:79-82); host pointers.

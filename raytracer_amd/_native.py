@@ -33,6 +33,8 @@ class RtStats(C.Structure):
         ("long_trace", C.c_uint64), ("long_shadow", C.c_uint64),
         ("max_lane_steps", C.c_uint64), ("max_wave_steps", C.c_uint64),
         ("bytes_fetched", C.c_uint64),
+        ("ms_shadow_main", C.c_double), ("bytes_fetched_main", C.c_uint64),
+        ("launches_shadow_main", C.c_uint32), ("speculative", C.c_uint32), ("respeculated", C.c_uint64),
     ]
 
     @property
@@ -44,6 +46,12 @@ class RtStats(C.Structure):
         d["rays_per_level"] = list(self.rays_per_level)
         d["rays"] = self.rays
         return d
+
+
+class RtCamera(C.Structure):
+    """rt_camera of include/rtgpu.h (camera.rs:5-27)"""
+    _fields_ = [("vw", C.c_int32), ("vh", C.c_int32), ("origin", C.c_double * 3),
+                ("yaw", C.c_double), ("pitch", C.c_double), ("fov", C.c_double), ("chf", C.c_double)]
 
 
 class RtRayHit(C.Structure):
@@ -78,6 +86,7 @@ _host = None
 GPU_SYMBOLS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload", "rt_render",
     "rt_shard_pixels", "rt_supertile", "rt_render_shard", "rt_detile", "rt_cast_rays", "rt_cast_rays_noalloc",
+    "rt_render_shard_batch", "rt_detile_frames",
 ]
 
 
@@ -103,6 +112,10 @@ def gpu():
         L.rt_render_shard.restype = C.c_int
         L.rt_detile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64, C.c_uint32, C.c_void_p]
         L.rt_detile.restype = C.c_int
+        L.rt_render_shard_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(RtStats)]
+        L.rt_render_shard_batch.restype = C.c_int
+        L.rt_detile_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int64, C.c_uint32, C.c_void_p]
+        L.rt_detile_frames.restype = C.c_int
         L.rt_cast_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_cast_rays.restype = C.c_int
         L.rt_cast_rays_noalloc.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -157,6 +170,7 @@ def host():
             "rth_sdl_load": ([C.c_char_p, C.c_int, C.c_char_p, dbl, C.c_uint64], vp),
             "rth_sdl_printed": ([], C.c_char_p),
             "rth_scene_counts": ([vp, C.POINTER(u32)], None),
+            "rth_camera_chf": ([dbl], dbl),
             "rth_write_png": ([C.c_char_p, u32, u32, vp], C.c_int),
             "rth_read_png": ([C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp], C.c_int),
             "rth_read_image": ([C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp], C.c_int),

@@ -900,7 +900,7 @@ __device__ uint32_t skybox_color(const DScene& S, D3 dir) {
 }
 
 // ---------------------------------------------------------------- camera.rs:55-67
-DEV D3 camera_direction(const DScene& S, double x, double y) {
+DEV D3 camera_direction(const DCamera& S, double x, double y) {
     double nx = x - S.half_w;
     double ny = y - S.half_h;
     D3 f = normalize(d3(nx, -ny, -S.cam_z));

@@ -104,11 +104,15 @@ struct DLight {
     double shadow_coefficient, max_distance;
 };
 
-struct DScene {
-    // camera (camera.rs:55-67): rot = from_euler_xyz(-pitch, yaw, 0) hoisted to the host
+// camera (camera.rs:55-67): rot = from_euler_xyz(-pitch, yaw, 0) hoisted to the host
+struct DCamera {
     double cam_o[3];
     double rot[3][3];
     double half_w, half_h, cam_z;   // vw*0.5, vh*0.5, vh*0.5*chf
+};
+
+struct DScene {
+    DCamera cam;
     int32_t vw, vh;
     uint32_t max_depth;
     uint32_t n_objects, n_lights, n_meshes;

@@ -32,7 +32,11 @@
 struct ShardMap {
     uint32_t shard, n_shards, supers_x, n_supers, super_shift, row_rot;
     uint32_t row_major_out;                       // 1: write the frame row-major; 0: compact slot order
+    // a launch may cover this shard of several frames: level 0 holds them back to back, per_frame slots each; in the
+    // compact output frame f starts at slot f * frame_stride (>= per_frame: the caller pads every shard to the largest)
+    uint32_t per_frame, frame_stride;
 };
+DEV size_t out_slot(const ShardMap& m, uint32_t i) { return (size_t)(i / m.per_frame) * m.frame_stride + i % m.per_frame; }
 
 DEV bool slot_pixel(const ShardMap& m, int32_t vw, int32_t vh, uint32_t slot, int32_t& x, int32_t& y) {
     const uint32_t sh = m.super_shift;
@@ -58,19 +62,31 @@ DEV void store_ray(const DLevel& L, uint32_t i, D3 o, D3 d) {
     L.rd[0][i] = d.x; L.rd[1][i] = d.y; L.rd[2][i] = d.z;
 }
 
-// Level 0 only: primary rays (scene.rs:210-217, camera.rs:55-59)
-__global__ __launch_bounds__(RT_BLOCK) void k_primary(const DScene* Sp, DLevel L, uint32_t n, ShardMap map) {
+// Level 0 only: primary rays (scene.rs:210-217, camera.rs:55-59).  A launch may cover the same shard of several frames
+// that differ in their camera only (a camera path through one scene): frame f = slot / per_frame looks through cams[f];
+// cams == nullptr: one frame, the scene's own camera.
+__global__ __launch_bounds__(RT_BLOCK) void k_primary(const DScene* Sp, const DCamera* cams, DLevel L, uint32_t n, ShardMap map) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= n) return;
     const DScene& S = *Sp;
+    const DCamera& cam = cams ? cams[i / map.per_frame] : S.cam;
     int32_t x, y;
-    if (!slot_pixel(map, S.vw, S.vh, i, x, y)) {
+    if (!slot_pixel(map, S.vw, S.vh, i % map.per_frame, x, y)) {
         L.hit_obj[i] = RT_INACTIVE;
         store_ray(L, i, d3(0., 0., 0.), d3(0., 0., 1.));
         return;
     }
     L.hit_obj[i] = RT_NONE;
-    store_ray(L, i, ld3(S.cam_o), camera_direction(S, (double)x, (double)y));
+    store_ray(L, i, ld3(cam.cam_o), camera_direction(cam, (double)x, (double)y));
+}
+
+// A level's size as its kernels see it: `n` is what the launch was sized for -- the size itself when the host knows
+// it, otherwise the room the level was given -- and n_dev, when not null, points at the real count in device memory
+// (the cursor the level above advanced while spawning).
+DEV uint32_t level_size(uint32_t n, const unsigned long long* n_dev) {
+    if (!n_dev) return n;
+    const unsigned long long real = *n_dev;
+    return real < n ? (uint32_t)real : n;
 }
 
 DEV uint32_t lane_id() { return __lane_id(); }
@@ -176,9 +192,11 @@ DEV void trace_finish(const DScene& S, DLevel& L, uint32_t i, bool active, const
 #endif
 // MESHES = false: a scene of analytic objects only (lane by lane, no budget): the mesh walks stay out of the kernel.
 template <bool COUNT, bool PACKET, bool BUDGET, bool FAR = true, bool MESHES = true>
-__global__ __launch_bounds__(RT_BLOCK) RT_TRACE_ATTR void k_trace(const DScene* Sp, DLevel L, uint32_t n, uint32_t* hitlist, double* hs, uint32_t stride,
+__global__ __launch_bounds__(RT_BLOCK) RT_TRACE_ATTR void k_trace(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, uint32_t* hitlist, double* hs, uint32_t stride,
                                                     DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    n = level_size(n, n_dev);
+    if (blockIdx.x * RT_BLOCK >= n) return;   // (a whole workgroup past the end: launches are sized for the level's room)
     const DScene& S = *Sp;
     Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0; vc.units = 0;
     bool active = i < n && L.hit_obj[i] != RT_INACTIVE;
@@ -378,15 +396,18 @@ DEV void light_shading(const DLight& Lt, const Ray& ray, const Hit& hit, bool sh
 // kernel (no LDS, a third of the registers), which matters because it sits on the frame's critical path beside a
 // chip full of shadow waves.
 template <bool COUNT, bool MESHREF>
-__global__ __launch_bounds__(RT_BLOCK) void k_spawn(const DScene* Sp, DLevel L, DLevel N, uint32_t n, uint32_t depth,
-                                                    uint32_t next_cap, DCounters* C, DLevelCounts* LC, uint32_t* ids_out) {
+__global__ __launch_bounds__(RT_BLOCK) void k_spawn(const DScene* Sp, DLevel L, DLevel N, uint32_t n, const unsigned long long* n_dev, uint32_t depth,
+                                                    uint32_t next_cap, DCounters* C, DLevelCounts* LC, uint32_t* ids_out, ShardMap map) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    n = level_size(n, n_dev);
+    if (blockIdx.x * RT_BLOCK >= n) return;
+    const size_t io = ids_out ? out_slot(map, i) : 0;   // (ids are written for level 0 only)
     const DScene& S = *Sp;
     bool active = i < n;
     uint32_t obj = active ? L.hit_obj[i] : RT_INACTIVE;
     if (active && obj == RT_INACTIVE) {
         L.result[i] = 0u; L.base_flags[i] = (uint32_t)NF_DONE << 24;
-        if (ids_out && depth == 0) { ids_out[2 * (size_t)i] = RT_NONE; ids_out[2 * (size_t)i + 1] = RT_NONE; }
+        if (ids_out && depth == 0) { ids_out[2 * io] = RT_NONE; ids_out[2 * io + 1] = RT_NONE; }
         active = false;
     }
     Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0; vc.units = 0;
@@ -398,11 +419,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_spawn(const DScene* Sp, DLevel L, 
         if (obj == RT_NONE) {                                        // scene.rs:99
             L.result[i] = skybox_color(S, ray.d);
             L.base_flags[i] = (uint32_t)NF_DONE << 24;
-            if (ids_out && depth == 0) { ids_out[2 * (size_t)i] = RT_NONE; ids_out[2 * (size_t)i + 1] = RT_NONE; }
+            if (ids_out && depth == 0) { ids_out[2 * io] = RT_NONE; ids_out[2 * io + 1] = RT_NONE; }
         } else {
             Hit hit;
             closest_hit_fill(S, ray, obj, L.hit_prim[i], L.hit_t[i], L.hit_t2[i], L.hit_u[i], L.hit_v[i], hit);
-            if (ids_out && depth == 0) { ids_out[2 * (size_t)i] = obj; ids_out[2 * (size_t)i + 1] = hit.prim; }
+            if (ids_out && depth == 0) { ids_out[2 * io] = obj; ids_out[2 * io + 1] = hit.prim; }
             const DMaterial& mat = S.materials[S.objects[obj].material];
             const uint32_t base_rgb = texture_at(mat, hit.u, hit.v);       // scene.rs:102
             if (mat.emissivity == 1.) {                                    // scene.rs:105-107
@@ -473,9 +494,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_spawn(const DScene* Sp, DLevel L, 
 
 // The lit colour of every hit that k_spawn left pending (scene.rs:102-122), from the shadow casts' results.  A hit
 // without children is final here; the others keep the colour for k_resolve.
-__global__ __launch_bounds__(RT_BLOCK) void k_light(const DScene* Sp, DLevel L, uint32_t n, const uint8_t* occ, uint32_t stride) {
+__global__ __launch_bounds__(RT_BLOCK) void k_light(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, const uint8_t* occ, uint32_t stride) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    if (i >= level_size(n, n_dev)) return;
     const uint32_t bf = L.base_flags[i];
     const uint32_t flags = bf >> 24;
     if (flags & NF_DONE) return;
@@ -510,10 +531,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_light(const DScene* Sp, DLevel L, 
 
 // Folds one level into its parents' view: scene.rs:176-205 on the children's
 // 8-bit results.  Level 0 also writes the frame.
-__global__ __launch_bounds__(RT_BLOCK) void k_resolve(const DScene* Sp, DLevel L, DLevel N, uint32_t n, int level0,
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(const DScene* Sp, DLevel L, DLevel N, uint32_t n, const unsigned long long* n_dev, int level0,
                                                       uint8_t* rgb_out, ShardMap map) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    if (i >= level_size(n, n_dev)) return;
     const uint32_t bf = L.base_flags[i];
     const uint32_t flags = bf >> 24;
     uint32_t res;
@@ -534,7 +555,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(const DScene* Sp, DLevel L
         L.result[i] = res;
     }
     if (level0) {
-        size_t o = i;
+        size_t o = out_slot(map, i);
         if (map.row_major_out) {
             const DScene& S = *Sp;
             int32_t x, y;
@@ -556,17 +577,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_ids_rowmajor(const DScene* Sp, con
     out[2 * o] = compact[2 * (size_t)i]; out[2 * o + 1] = compact[2 * (size_t)i + 1];
 }
 
-// Gathered compact shard buffers -> row-major image (rt_detile)
-__global__ __launch_bounds__(RT_BLOCK) void k_detile(const uint8_t* gathered, uint8_t* image, int32_t vw, int32_t vh, uint32_t n_shards,
+// Gathered compact shard buffers -> row-major images (rt_detile, rt_detile_frames).  Layout of `gathered`:
+// [shard][frame][slot], every (shard, frame) run padded to slots_per_shard slots; image f starts at f * vw * vh elements.
+__global__ __launch_bounds__(RT_BLOCK) void k_detile(const uint8_t* gathered, uint8_t* images, int32_t vw, int32_t vh, uint32_t n_shards, uint32_t n_frames,
                                                      unsigned long long slots_per_shard, uint32_t elem_bytes, ShardMap m) {
     const unsigned long long g = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-    const unsigned long long total = slots_per_shard * n_shards;
+    const unsigned long long total = slots_per_shard * n_shards * n_frames;
     if (g >= total) return;
-    m.shard = (uint32_t)(g / slots_per_shard);
+    const unsigned long long run = g / slots_per_shard;
+    m.shard = (uint32_t)(run / n_frames);
+    const uint32_t frame = (uint32_t)(run % n_frames);
     int32_t x, y;
     if (!slot_pixel(m, vw, vh, (uint32_t)(g % slots_per_shard), x, y)) return;
     const uint8_t* src = gathered + g * elem_bytes;
-    uint8_t* dst = image + ((size_t)y * (size_t)vw + (size_t)x) * elem_bytes;
+    uint8_t* dst = images + (((size_t)frame * (size_t)vh + (size_t)y) * (size_t)vw + (size_t)x) * elem_bytes;
     for (uint32_t b = 0; b < elem_bytes; b++) dst[b] = src[b];
 }
 

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "../../include/rtgpu.h"
@@ -37,9 +38,10 @@ struct LevelWork {
     void* hs = nullptr; size_t hs_cap = 0;             // hit point + shadow-ray origin of every lit hit, 6 planes of doubles
     void* long_trace = nullptr; size_t long_trace_cap = 0;     // long-ray lists
     void* long_shadow = nullptr; size_t long_shadow_cap = 0;
-    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // see LW_*
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // see LW_*
 };
-enum { LW_T0, LW_T1, LW_P, LW_S0, LW_S1, LW_L0, LW_L1 };
+enum { LW_T0, LW_T1, LW_P, LW_S0, LW_SK, LW_S1, LW_L0, LW_L1 };
+#define RT_MAX_LEVELS 9   /* trace_ray depths 0..max_ray_depth (at most 7), and one more for the counters' sake */
 #define RT_SIDE_STREAMS 4
 
 }  // namespace
@@ -91,11 +93,13 @@ struct rt_ctx {
     int32_t vw = 0, vh = 0;
     uint32_t max_depth = 0;
     std::vector<LevelAlloc> levels;
-    DCounters* dcounters = nullptr;
+    DCounters* dcounters = nullptr;   // [RT_MAX_LEVELS], one set per trace_ray depth
     DCounters* hcounters = nullptr;   // pinned
     void* d_out = nullptr; size_t d_out_cap = 0;      // rgb staging for rt_render
     void* d_ids = nullptr; size_t d_ids_cap = 0;      // compact ids
     void* d_ids2 = nullptr; size_t d_ids2_cap = 0;    // row-major ids
+    void* d_cams = nullptr; size_t d_cams_cap = 0;    // cameras of a batch of frames (rt_render_shard_batch)
+    std::vector<DCamera> h_cams;
     std::vector<LevelWork> lw;
     DLevelCounts* d_lcounts = nullptr;                // [n_lcounts], one pair of cursors per level
     DLevelCounts* h_lcounts = nullptr;                // pinned
@@ -114,6 +118,11 @@ struct rt_ctx {
     int count_visits = 0;                             // RTGPU_COUNT_VISITS: bit 0 k_trace, bit 1 k_shadow, bit 2 k_shade instrumented
     uint32_t n_lights = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // level sizes of the last frame rendered for (shard, n_shards, vw, vh, max_depth): what the next such frame is given room for
+    typedef std::tuple<uint32_t, uint32_t, int32_t, int32_t, uint32_t, uint32_t> LearnedKey;
+    std::map<LearnedKey, std::vector<uint64_t>> learned;
+    bool sync_levels = false;                         // RTGPU_SYNC_LEVELS=1: always read each level's size back before the next
+    uint64_t respeculated = 0;                        // frames rendered twice because a level outgrew its room
     size_t scene_bytes = 0, work_bytes = 0;
     double ms_upload = 0.;
 };
@@ -184,6 +193,16 @@ void camera_rotation(double pitch, double yaw, double rot[3][3]) {
     M4 cc = {{{cz, -sz, 0., 0.}, {sz, cz, 0., 0.}, {0., 0., 1., 0.}, {0., 0., 0., 1.}}};
     M4 r = m4mul(m4mul(a, b), cc);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rot[i][j] = r.a[i][j];
+}
+
+DCamera make_camera(const rt_camera& cam) {
+    DCamera d;
+    for (int k = 0; k < 3; k++) d.cam_o[k] = cam.origin[k];
+    camera_rotation(cam.pitch, cam.yaw, d.rot);
+    d.half_w = (double)cam.vw * 0.5;               // camera.rs:63
+    d.half_h = (double)cam.vh * 0.5;               // :64
+    d.cam_z = (double)cam.vh * 0.5 * cam.chf;      // :65
+    return d;
 }
 
 // Re-emits one mesh: DFS-preorder host nodes (rt_bvh_node) -> inner-node array
@@ -487,6 +506,8 @@ ShardMap make_map(int32_t vw, int32_t vh, uint32_t shard, uint32_t n_shards, uin
     m.n_supers = m.supers_x * (uint32_t)((vh + side - 1) / side);
     m.row_rot = shard_row_rotation(m.supers_x, n_shards);
     m.row_major_out = row_major;
+    const int64_t px = rt_shard_pixels(vw, vh, shard, n_shards);
+    m.per_frame = m.frame_stride = px > 0 ? (uint32_t)px : 1u;
     return m;
 }
 
@@ -529,51 +550,87 @@ int ensure_level_counts(rt_ctx* c, size_t n) {
 
 // The frame: levels 0..max_depth forward, then folded back.
 //
-// Main stream:  k_primary, then per level d  k_trace(d) -> k_spawn(d) -> read back the size of level d+1.
+// Main stream:  k_primary, then per level d  k_trace(d) -> k_spawn(d).
 // Side streams: per level d  k_shadow(d) -> k_light(d), both after k_spawn(d).
 // The shadow casts of a level need only that level's hits, and the next level needs only the spawned rays, so the
 // two chains run side by side: the long tail of a shadow launch (a few rays that skim the whole mesh) overlaps with
 // the trace of the deeper levels instead of idling the chip.  k_resolve waits for every k_light.
-int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st) {
+//
+// How many rays a level holds is only known on the device, once the level above has spawned them.  A frame can be
+// rendered two ways:
+//   measured    (learned == nullptr) after each level the host reads the count back (one stream synchronisation per
+//               level), sizes the next level's buffers for the worst case (two children per ray) and its launches
+//               exactly;
+//   speculative (learned = the level sizes of an earlier frame of this context and shard) every launch of the frame
+//               is queued at once: level d is given room for a quarter more rays than it held last time, its launches
+//               are sized for that room and read the real count from device memory.  If a level outgrows its room
+//               the frame is rendered again the measured way (`overflow`); a sequence's frames resemble each other,
+//               so that is rare.  No host round trip inside the frame: the launches of a small shard (a 1/8 frame is
+//               1.5 ms of GPU work) are not held up by five waits for the host.
+//
+// n_frames > 1: the same shard of n_frames frames that differ in their camera only (d_cams, device memory), as one
+// set of launches: level 0 holds the frames' primary rays one frame after the other, and nothing below level 0
+// knows of frames.  Eight 1/8-frame shards make launches as large as a whole frame's, and a GPU that owns one shard
+// of a sequence works as efficiently as a GPU that owns whole frames.
+int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint32_t n_frames, const DCamera* d_cams, uint32_t frame_stride,
+                      uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st,
+                      const std::vector<uint64_t>* learned, bool& overflow, std::vector<uint64_t>& level_sizes) {
+    overflow = false;
     if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
     HIP_TRY(c, hipSetDevice(c->device));
     const int64_t n0s = rt_shard_pixels(c->vw, c->vh, shard, n_shards);
     if (n0s < 0) return fail(c, RT_ERR_INVALID, "bad shard arguments");
-    if ((uint64_t)n0s >= 0x7FFFFFFFull) return fail(c, RT_ERR_UNSUPPORTED, "frame too large for one shard");
-    const uint32_t n0 = (uint32_t)n0s;
+    if ((uint64_t)n0s * n_frames >= 0x7FFFFFFFull) return fail(c, RT_ERR_UNSUPPORTED, "frame (or batch of frames) too large for one set of launches");
+    const uint32_t per_frame = (uint32_t)n0s;
+    const uint32_t n0 = per_frame * n_frames;
     ShardMap map = make_map(c->vw, c->vh, shard, n_shards, row_major);
+    if (n_frames > 1) map.frame_stride = frame_stride;
     rt_stats stats; std::memset(&stats, 0, sizeof(stats));
-    stats.rays_primary = valid_pixels(map, c->vw, c->vh);
+    stats.rays_primary = valid_pixels(map, c->vw, c->vh) * n_frames;
     stats.rays_per_level[0] = stats.rays_primary;
     hipStream_t s = c->stream;
     int rc;
     const size_t n_lc = (size_t)c->max_depth + 2;
+    if (n_lc > RT_MAX_LEVELS) return fail(c, RT_ERR_UNSUPPORTED, "max_ray_depth above 7 is not supported");
     if ((rc = ensure_level_counts(c, n_lc)) != RT_OK) return rc;
-    std::memset(c->hcounters, 0, sizeof(DCounters));
-    HIP_TRY(c, hipMemsetAsync(c->dcounters, 0, sizeof(DCounters), s));
+    std::memset(c->hcounters, 0, RT_MAX_LEVELS * sizeof(DCounters));
+    HIP_TRY(c, hipMemsetAsync(c->dcounters, 0, RT_MAX_LEVELS * sizeof(DCounters), s));
     HIP_TRY(c, hipMemsetAsync(c->d_lcounts, 0, n_lc * sizeof(DLevelCounts), s));
 
-    std::vector<uint32_t> counts;
-    counts.push_back(n0);
-    uint32_t n_tr = 0, n_sh = 0, n_sd = 0;
+    // room per level: exact for level 0; measured frames learn the others as they go
+    std::vector<uint32_t> room;
+    room.push_back(n0);
+    if (learned) {
+        for (size_t d = 1; d < learned->size() && d <= c->max_depth; d++) {
+            const uint64_t worst = std::min<uint64_t>(2ull * room[d - 1], 0x7FFFFFFEull);
+            const uint64_t want = (*learned)[d] + (*learned)[d] / 4 + 4096;
+            room.push_back((uint32_t)std::min(worst, want));
+        }
+    }
+    std::vector<uint8_t> main_shadow(RT_MAX_LEVELS, 0);   // levels whose shadow casts ran as the budget-free packet kernel
+    uint32_t n_tr = 0, n_sh = 0, n_sd = 0, n_main = 0;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     if (n0 > 0) {
         if ((rc = ensure_level(c, 0, n0)) != RT_OK) return rc;
-        hipLaunchKernelGGL(k_primary, dim3((n0 + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, c->dscene, c->levels[0].lv, n0, map);
+        hipLaunchKernelGGL(k_primary, dim3((n0 + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, c->dscene, d_cams, c->levels[0].lv, n0, map);
     }
-    for (uint32_t depth = 0; depth < counts.size(); depth++) {
-        const uint32_t n = counts[depth];
+    for (uint32_t depth = 0; depth < room.size(); depth++) {
+        const uint32_t n = room[depth];   // rays of this level (measured) or the room given to it (speculative)
         if (n == 0) break;
-        // worst case every ray spawns two children (scene.rs:134-172)
+        // the level's real size, for the kernels: on the device when it is not known here
+        const unsigned long long* n_dev = (learned && depth > 0) ? &c->d_lcounts[depth - 1].next_count : nullptr;
         const bool can_spawn = depth < c->max_depth;
-        const size_t next_cap = can_spawn ? std::min<size_t>((size_t)2 * n, 0x7FFFFFFEull) : 1;
-        if ((rc = ensure_level(c, depth + 1, next_cap)) != RT_OK) return rc;
+        // measured: worst case, every ray spawns two children (scene.rs:134-172)
+        const size_t next_cap = learned ? (depth + 1 < room.size() ? room[depth + 1] : 0)
+                                        : (can_spawn ? std::min<size_t>((size_t)2 * n, 0x7FFFFFFEull) : 0);
+        if ((rc = ensure_level(c, depth + 1, std::max<size_t>(next_cap, 1))) != RT_OK) return rc;
         if ((rc = ensure_level_work(c, depth, n)) != RT_OK) return rc;
         LevelWork& W = c->lw[depth];
         double* hs = static_cast<double*>(W.hs);
         uint32_t* hitlist = static_cast<uint32_t*>(W.hitlist);
         uint8_t* occ = static_cast<uint8_t*>(W.occ);
         DLevelCounts* lc = c->d_lcounts + depth;
+        DCounters* dc = c->dcounters + depth;
         uint32_t* long_trace = static_cast<uint32_t*>(W.long_trace);
         uint32_t* long_shadow = static_cast<uint32_t*>(W.long_shadow);
         // budgets only where the launch is small enough for its slowest wave to set its duration: in a large
@@ -587,7 +644,7 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
         // (and scenes of analytic objects only, whose object tree is walked per lane anyway) lane by lane
         {
             auto launch = [&](auto kern) {
-                hipLaunchKernelGGL(kern, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, hitlist, hs, n, c->dcounters, lc, long_trace, lp);
+                hipLaunchKernelGGL(kern, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, n_dev, hitlist, hs, n, dc, lc, long_trace, lp);
             };
             const bool cnt = (c->count_visits & 1) != 0;
             if (c->hscene.n_meshes == 0) { if (cnt) launch(k_trace<true, false, false, false, false>); else launch(k_trace<false, false, false, false, false>); }
@@ -600,14 +657,14 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
             else { if (cnt) launch(k_trace<true, false, false, false>); else launch(k_trace<false, false, false, false>); }
         }
         if (depth > 0 && lp.budget_lane) {
-            if (c->count_visits & 1) hipLaunchKernelGGL(k_long_trace<true>, dim3(RT_LONG_BLOCKS), block, 0, s, c->dscene, c->levels[depth].lv, long_trace, hitlist, hs, n, c->dcounters, lc);
-            else hipLaunchKernelGGL(k_long_trace<false>, dim3(RT_LONG_BLOCKS), block, 0, s, c->dscene, c->levels[depth].lv, long_trace, hitlist, hs, n, c->dcounters, lc);
+            if (c->count_visits & 1) hipLaunchKernelGGL(k_long_trace<true>, dim3(RT_LONG_BLOCKS), block, 0, s, c->dscene, c->levels[depth].lv, long_trace, hitlist, hs, n, dc, lc);
+            else hipLaunchKernelGGL(k_long_trace<false>, dim3(RT_LONG_BLOCKS), block, 0, s, c->dscene, c->levels[depth].lv, long_trace, hitlist, hs, n, dc, lc);
         }
         HIP_TRY(c, hipEventRecord(W.ev[LW_T1], s));
         {
             auto launch = [&](auto kern) {
-                hipLaunchKernelGGL(kern, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, depth,
-                                   (uint32_t)next_cap, c->dcounters, lc, depth == 0 ? d_ids : nullptr);
+                hipLaunchKernelGGL(kern, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, n_dev, depth,
+                                   (uint32_t)next_cap, dc, lc, depth == 0 ? d_ids : nullptr, map);
             };
             const bool cnt = (c->count_visits & 4) != 0;
             if (c->any_mesh_refracts) { if (cnt) launch(k_spawn<true, true>); else launch(k_spawn<false, true>); }
@@ -618,78 +675,99 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
         // path, and next to a chip full of shadow waves it would crawl
         HIP_TRY(c, hipStreamWaitEvent(side, W.ev[LW_P], 0));
         HIP_TRY(c, hipEventRecord(W.ev[LW_S0], side));
+        bool main_variant = false;
         if (c->n_lights) {
             // sized for the worst case (every ray hit); threads past the hit count leave at once
             const dim3 sgrid((n + RT_BLOCK - 1) / RT_BLOCK, c->n_lights);
             if (c->hscene.n_meshes == 0) {
                 lp.budget_wave = 0;   // (no long-ray pass: nothing is walked as a packet)
-                hipLaunchKernelGGL(k_shadow_lanes<false>, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc);
+                hipLaunchKernelGGL(k_shadow_lanes<false>, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc);
             } else {
-                auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc, long_shadow, lp); };
+                auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc, long_shadow, lp); };
                 const bool cnt = (c->count_visits & 2) != 0;
                 if (lp.budget_wave) { if (cnt) launch(k_shadow<true, true>); else launch(k_shadow<false, true>); }
-                else { if (cnt) launch(k_shadow<true, false>); else launch(k_shadow<false, false>); }
+                else { main_variant = true; if (cnt) launch(k_shadow<true, false>); else launch(k_shadow<false, false>); }
             }
+        }
+        HIP_TRY(c, hipEventRecord(W.ev[LW_SK], side));
+        if (c->n_lights) {
             if (lp.budget_wave) {
-                if (c->count_visits & 2) hipLaunchKernelGGL(k_long_shadow<true>, dim3(RT_LONG_BLOCKS), block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc, long_shadow);
-                else hipLaunchKernelGGL(k_long_shadow<false>, dim3(RT_LONG_BLOCKS), block, 0, side, c->dscene, hitlist, hs, occ, n, c->dcounters, lc, long_shadow);
+                if (c->count_visits & 2) hipLaunchKernelGGL(k_long_shadow<true>, dim3(RT_LONG_BLOCKS), block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc, long_shadow);
+                else hipLaunchKernelGGL(k_long_shadow<false>, dim3(RT_LONG_BLOCKS), block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc, long_shadow);
             }
             n_sd++;
         }
+        if (main_variant) { main_shadow[depth] = 1; n_main++; }
         HIP_TRY(c, hipEventRecord(W.ev[LW_S1], side));
         HIP_TRY(c, hipEventRecord(W.ev[LW_L0], side));
-        hipLaunchKernelGGL(k_light, grid, block, 0, side, c->dscene, c->levels[depth].lv, n, occ, n);
+        hipLaunchKernelGGL(k_light, grid, block, 0, side, c->dscene, c->levels[depth].lv, n, n_dev, occ, n);
         HIP_TRY(c, hipEventRecord(W.ev[LW_L1], side));
         n_tr++; n_sh++;
-        HIP_TRY(c, hipMemcpyAsync(c->h_lcounts + depth, lc, sizeof(DLevelCounts), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        HIP_TRY(c, hipGetLastError());
-        const unsigned long long spawned = c->h_lcounts[depth].next_count;
-        if (spawned > next_cap) return fail(c, RT_ERR_DEVICE, "wavefront level overflow");
-        if (spawned > 0 && can_spawn) {
-            counts.push_back((uint32_t)spawned);
-            if (depth + 1 < 8) stats.rays_per_level[depth + 1] = spawned;
+        if (!learned) {
+            HIP_TRY(c, hipMemcpyAsync(c->h_lcounts + depth, lc, sizeof(DLevelCounts), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            HIP_TRY(c, hipGetLastError());
+            const unsigned long long spawned = c->h_lcounts[depth].next_count;
+            if (spawned > next_cap) return fail(c, RT_ERR_DEVICE, "wavefront level overflow");
+            if (spawned > 0 && can_spawn) room.push_back((uint32_t)spawned);
         }
     }
-    const size_t used = std::min<size_t>(counts.size(), c->lw.size());
-    for (size_t d = 0; d < used; d++) if (counts[d] > 0) HIP_TRY(c, hipStreamWaitEvent(s, c->lw[d].ev[LW_L1], 0));
+    size_t n_levels = 0;
+    while (n_levels < room.size() && room[n_levels] > 0) n_levels++;
+    const size_t used = std::min<size_t>(n_levels, c->lw.size());
+    for (size_t d = 0; d < used; d++) HIP_TRY(c, hipStreamWaitEvent(s, c->lw[d].ev[LW_L1], 0));
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
-    for (int depth = (int)counts.size() - 1; depth >= 0; depth--) {
-        const uint32_t n = counts[depth];
-        if (n == 0) continue;
+    for (int depth = (int)n_levels - 1; depth >= 0; depth--) {
+        const uint32_t n = room[depth];
+        const unsigned long long* n_dev = (learned && depth > 0) ? &c->d_lcounts[depth - 1].next_count : nullptr;
         hipLaunchKernelGGL(k_resolve, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, c->dscene, c->levels[depth].lv,
-                           c->levels[depth + 1].lv, n, depth == 0 ? 1 : 0, d_rgb, map);
+                           c->levels[depth + 1].lv, n, n_dev, depth == 0 ? 1 : 0, d_rgb, map);
     }
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
-    HIP_TRY(c, hipMemcpyAsync(c->hcounters, c->dcounters, sizeof(DCounters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->hcounters, c->dcounters, RT_MAX_LEVELS * sizeof(DCounters), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(c->h_lcounts, c->d_lcounts, n_lc * sizeof(DLevelCounts), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
-    for (size_t d = 0; d < counts.size() && d < n_lc; d++) { stats.long_trace += c->h_lcounts[d].long_trace; stats.long_shadow += c->h_lcounts[d].long_shadow; }
+    // what the levels really held; a speculative frame whose level outgrew its room has dropped rays and is void
+    level_sizes.assign(1, n0);
+    for (size_t d = 0; d + 1 < n_lc; d++) {
+        const unsigned long long spawned = c->h_lcounts[d].next_count;
+        if (spawned == 0 || d >= n_levels) { if (spawned != 0) overflow = true; break; }
+        const unsigned long long had_room = d + 1 < room.size() ? room[d + 1] : 0;
+        if (spawned > had_room) overflow = true;
+        level_sizes.push_back(spawned);
+        if (d + 1 < 8) stats.rays_per_level[d + 1] = spawned;
+    }
+    if (overflow) return RT_OK;
+    for (size_t d = 0; d < n_levels && d < n_lc; d++) { stats.long_trace += c->h_lcounts[d].long_trace; stats.long_shadow += c->h_lcounts[d].long_shadow; }
     // per-phase times are sums of the launches' own durations; the phases overlap, so they add up to more than ms_render
-    float ms_trace = 0.f, ms_shadow = 0.f, ms_shade = 0.f, ms_resolve = 0.f, ms_all = 0.f;
+    float ms_trace = 0.f, ms_shadow = 0.f, ms_shade = 0.f, ms_resolve = 0.f, ms_all = 0.f, ms_main = 0.f;
     for (size_t d = 0; d < used; d++) {
-        if (counts[d] == 0) continue;
         const LevelWork& W = c->lw[d];
-        float a = 0.f, b = 0.f, p = 0.f, l = 0.f;
+        float a = 0.f, b = 0.f, p = 0.f, l = 0.f, k = 0.f;
         (void)hipEventElapsedTime(&a, W.ev[LW_T0], W.ev[LW_T1]);
         (void)hipEventElapsedTime(&b, W.ev[LW_S0], W.ev[LW_S1]);
         (void)hipEventElapsedTime(&p, W.ev[LW_T1], W.ev[LW_P]);
         (void)hipEventElapsedTime(&l, W.ev[LW_L0], W.ev[LW_L1]);
+        if (main_shadow[d]) { (void)hipEventElapsedTime(&k, W.ev[LW_S0], W.ev[LW_SK]); ms_main += k; }
         ms_trace += a; ms_shadow += b; ms_shade += p + l;
     }
     (void)hipEventElapsedTime(&ms_resolve, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&ms_all, c->ev[0], c->ev[2]);
-    for (int k = 0; k < RT_SHARDS; k++) {
-        const DShard& sh = c->hcounters->shard[k];
-        stats.rays_reflect += sh.rays_reflect; stats.rays_transmit += sh.rays_transmit; stats.rays_shadow += sh.rays_shadow;
-        stats.nodes_visited += sh.nodes_visited; stats.tris_tested += sh.tris_tested;
-        stats.wave_nodes += sh.wave_nodes; stats.wave_tris += sh.wave_tris;
-        stats.bytes_fetched += 16ull * sh.units_fetched;
-        stats.max_lane_steps = std::max<uint64_t>(stats.max_lane_steps, sh.max_lane_steps); stats.max_wave_steps = std::max<uint64_t>(stats.max_wave_steps, sh.max_wave_steps);
-    }
+    for (size_t d = 0; d < RT_MAX_LEVELS; d++)
+        for (int k = 0; k < RT_SHARDS; k++) {
+            const DShard& sh = c->hcounters[d].shard[k];
+            stats.rays_reflect += sh.rays_reflect; stats.rays_transmit += sh.rays_transmit; stats.rays_shadow += sh.rays_shadow;
+            stats.nodes_visited += sh.nodes_visited; stats.tris_tested += sh.tris_tested;
+            stats.wave_nodes += sh.wave_nodes; stats.wave_tris += sh.wave_tris;
+            stats.bytes_fetched += 16ull * sh.units_fetched;
+            if (main_shadow[d]) stats.bytes_fetched_main += 16ull * sh.units_fetched;
+            stats.max_lane_steps = std::max<uint64_t>(stats.max_lane_steps, sh.max_lane_steps); stats.max_wave_steps = std::max<uint64_t>(stats.max_wave_steps, sh.max_wave_steps);
+        }
     stats.ms_render = ms_all; stats.ms_trace = ms_trace; stats.ms_shadow = ms_shadow; stats.ms_shade = ms_shade; stats.ms_resolve = ms_resolve;
+    stats.ms_shadow_main = ms_main; stats.launches_shadow_main = n_main;
     stats.launches_trace = n_tr; stats.launches_shadow = n_sd; stats.launches_shade = n_sh;
+    stats.speculative = learned ? 1u : 0u;
     stats.ms_upload = c->ms_upload;
     stats.device_bytes = c->scene_bytes + c->work_bytes;
     if (st) *st = stats;
@@ -699,8 +777,21 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
 // Every error exit of a frame passes through here: kernels of earlier levels may still be writing the level buffers,
 // the occlusion bytes or the caller's output buffer on the main and side streams, and the caller may free that
 // buffer as soon as it sees the error code.
-int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st) {
-    const int rc = render_frame_impl(c, shard, n_shards, row_major, d_rgb, d_ids, st);
+int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st,
+                 uint32_t n_frames = 1, const DCamera* d_cams = nullptr, uint32_t frame_stride = 0) {
+    // the level sizes this context last saw for this shard of this frame size: the next frame is queued without
+    // waiting for its own (see render_frame_impl); RTGPU_SYNC_LEVELS=1 turns that off
+    const rt_ctx::LearnedKey key{shard, n_shards, c->vw, c->vh, c->max_depth, n_frames};
+    auto it = c->sync_levels ? c->learned.end() : c->learned.find(key);
+    bool overflow = false;
+    std::vector<uint64_t> sizes;
+    int rc = render_frame_impl(c, shard, n_shards, row_major, n_frames, d_cams, frame_stride, d_rgb, d_ids, st, it != c->learned.end() ? &it->second : nullptr, overflow, sizes);
+    if (rc == RT_OK && overflow) {
+        c->respeculated++;
+        rc = render_frame_impl(c, shard, n_shards, row_major, n_frames, d_cams, frame_stride, d_rgb, d_ids, st, nullptr, overflow, sizes);
+        if (rc == RT_OK && overflow) rc = fail(c, RT_ERR_DEVICE, "wavefront level overflow");
+    }
+    if (rc == RT_OK) { c->learned[key] = sizes; if (st) st->respeculated = c->respeculated; }
     if (rc != RT_OK) {
         const std::string keep = c->err;
         if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -744,6 +835,7 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         if (const char* b = std::getenv("RTGPU_BUDGET_LANE")) c->long_params.budget_lane = (uint32_t)std::strtoul(b, nullptr, 10);
         if (const char* b = std::getenv("RTGPU_BUDGET_WAVE")) c->long_params.budget_wave = (uint32_t)std::strtoul(b, nullptr, 10);
         c->serial = std::getenv("RTGPU_SERIAL") != nullptr;
+        if (const char* b = std::getenv("RTGPU_SYNC_LEVELS")) c->sync_levels = std::strtol(b, nullptr, 10) != 0;
         if (const char* b = std::getenv("RTGPU_PACKET_DEPTH")) c->packet_depth = (uint32_t)std::strtoul(b, nullptr, 10);
         if (const char* b = std::getenv("RTGPU_BUDGET_BELOW")) c->long_below = (uint32_t)std::strtoul(b, nullptr, 10);
     }
@@ -753,11 +845,15 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     if ((e = scratch_address(device_id, &c->scratch)) != hipSuccess) return bail("hipGetSymbolAddress", e);
     // (all streams at the default priority: mixed priorities hung the frame on this ROCm)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    // Queued all at once (no level sizes read back), a frame's five shadow chains wait in the hardware queues for events
+    // far ahead and hold up whatever shares those queues: two side streams then serve better than four (4 % on
+    // the whole frame with four frames in flight).
+    c->n_side = c->sync_levels ? RT_SIDE_STREAMS : 2;
     if (const char* b = std::getenv("RTGPU_SIDE_STREAMS")) c->n_side = std::min<uint32_t>(RT_SIDE_STREAMS, std::max<uint32_t>(1, (uint32_t)std::strtoul(b, nullptr, 10)));
     for (uint32_t k = 0; k < c->n_side; k++) if ((e = hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipMalloc((void**)&c->dscene, sizeof(DScene))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc((void**)&c->dcounters, sizeof(DCounters))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipHostMalloc((void**)&c->hcounters, sizeof(DCounters), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    if ((e = hipMalloc((void**)&c->dcounters, RT_MAX_LEVELS * sizeof(DCounters))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipHostMalloc((void**)&c->hcounters, RT_MAX_LEVELS * sizeof(DCounters), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
     for (auto& ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     *out = c;
     return RT_OK;
@@ -785,6 +881,7 @@ void rt_ctx_destroy(rt_ctx* c) {
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ids) (void)hipFree(c->d_ids);
     if (c->d_ids2) (void)hipFree(c->d_ids2);
+    if (c->d_cams) (void)hipFree(c->d_cams);
     if (c->dscene) (void)hipFree(c->dscene);
     if (c->dcounters) (void)hipFree(c->dcounters);
     if (c->hcounters) (void)hipHostFree(c->hcounters);
@@ -839,11 +936,7 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     }
     DScene& H = c->hscene;
     std::memset(&H, 0, sizeof(H));
-    for (int k = 0; k < 3; k++) H.cam_o[k] = d->camera.origin[k];
-    camera_rotation(d->camera.pitch, d->camera.yaw, H.rot);
-    H.half_w = (double)d->camera.vw * 0.5;               // camera.rs:63
-    H.half_h = (double)d->camera.vh * 0.5;               // :64
-    H.cam_z = (double)d->camera.vh * 0.5 * d->camera.chf;   // :65
+    H.cam = make_camera(d->camera);
     H.vw = d->camera.vw; H.vh = d->camera.vh;
     H.max_depth = d->options.max_ray_depth;
     for (int k = 0; k < 3; k++) H.ambient[k] = (double)d->options.ambient[k] / 255.;   // vector.rs:216-224
@@ -1076,21 +1169,55 @@ int rt_render_shard(rt_ctx* c, uint32_t shard, uint32_t n_shards, void* d_rgb, v
     return RT_OK;
 }
 
-int rt_detile(rt_ctx* c, const void* d_gathered, uint32_t n_shards, int64_t slots_per_shard, uint32_t elem_bytes, void* d_image) {
+int rt_render_shard_batch(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t n_frames, const rt_camera* cameras,
+                          int64_t frame_stride, void* d_rgb, void* d_ids, rt_stats* stats_out) {
+    if (!c) return RT_ERR_INVALID;
+    if (!d_rgb) return fail(c, RT_ERR_INVALID, "d_rgb is NULL");
+    if (n_shards == 0 || shard >= n_shards) return fail(c, RT_ERR_INVALID, "bad shard arguments");
+    if (n_frames == 0 || n_frames > RT_BATCH_MAX) return fail(c, RT_ERR_INVALID, "rt_render_shard_batch: n_frames must be 1.." + std::to_string(RT_BATCH_MAX));
+    if (!cameras) return fail(c, RT_ERR_INVALID, "rt_render_shard_batch: cameras is NULL");
+    if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
+    if (frame_stride < rt_shard_pixels(c->vw, c->vh, shard, n_shards) || frame_stride >= 0x7FFFFFFFll)
+        return fail(c, RT_ERR_INVALID, "rt_render_shard_batch: frame_stride smaller than the shard (rt_shard_pixels)");
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->h_cams.resize(n_frames);
+    for (uint32_t f = 0; f < n_frames; f++) {
+        if (cameras[f].vw != c->vw || cameras[f].vh != c->vh)
+            return fail(c, RT_ERR_INVALID, "rt_render_shard_batch: camera " + std::to_string(f) + " has another frame size than the uploaded scene");
+        c->h_cams[f] = make_camera(cameras[f]);
+    }
+    int rc;
+    if ((rc = ensure_buf(c, &c->d_cams, &c->d_cams_cap, RT_BATCH_MAX * sizeof(DCamera))) != RT_OK) return rc;
+    // (pageable host memory: the copy has left h_cams when the call returns)
+    HIP_TRY(c, hipMemcpyAsync(c->d_cams, c->h_cams.data(), n_frames * sizeof(DCamera), hipMemcpyHostToDevice, c->stream));
+    rt_stats st;
+    rc = render_frame(c, shard, n_shards, 0, static_cast<uint8_t*>(d_rgb), static_cast<uint32_t*>(d_ids), &st, n_frames, static_cast<const DCamera*>(c->d_cams), (uint32_t)frame_stride);
+    if (rc != RT_OK) return rc;
+    st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (stats_out) *stats_out = st;
+    return RT_OK;
+}
+
+int rt_detile_frames(rt_ctx* c, const void* d_gathered, uint32_t n_shards, uint32_t n_frames, int64_t slots_per_shard, uint32_t elem_bytes, void* d_images) {
     if (!c) return RT_ERR_INVALID;
     if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
-    if (!d_gathered || !d_image || n_shards == 0 || slots_per_shard <= 0 || (elem_bytes != 3 && elem_bytes != 8)) return fail(c, RT_ERR_INVALID, "rt_detile: bad arguments");
+    if (!d_gathered || !d_images || n_shards == 0 || n_frames == 0 || slots_per_shard <= 0 || (elem_bytes != 3 && elem_bytes != 8)) return fail(c, RT_ERR_INVALID, "rt_detile: bad arguments");
     for (uint32_t s = 0; s < n_shards; s++)
         if (rt_shard_pixels(c->vw, c->vh, s, n_shards) > slots_per_shard) return fail(c, RT_ERR_INVALID, "rt_detile: slots_per_shard smaller than a shard");
     HIP_TRY(c, hipSetDevice(c->device));
     ShardMap map = make_map(c->vw, c->vh, 0, n_shards, 1);
-    const unsigned long long total = (unsigned long long)slots_per_shard * n_shards;
+    const unsigned long long total = (unsigned long long)slots_per_shard * n_shards * n_frames;
     if (total >= (1ull << 40)) return fail(c, RT_ERR_UNSUPPORTED, "rt_detile: too many slots");
     hipLaunchKernelGGL(k_detile, dim3((unsigned)((total + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, c->stream, static_cast<const uint8_t*>(d_gathered),
-                       static_cast<uint8_t*>(d_image), c->vw, c->vh, n_shards, (unsigned long long)slots_per_shard, elem_bytes, map);
+                       static_cast<uint8_t*>(d_images), c->vw, c->vh, n_shards, n_frames, (unsigned long long)slots_per_shard, elem_bytes, map);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     return RT_OK;
+}
+
+int rt_detile(rt_ctx* c, const void* d_gathered, uint32_t n_shards, int64_t slots_per_shard, uint32_t elem_bytes, void* d_image) {
+    return rt_detile_frames(c, d_gathered, n_shards, 1, slots_per_shard, elem_bytes, d_image);
 }
 
 int rt_cast_rays(rt_ctx* c, uint32_t n, const double* origins, const double* dirs, rt_ray_hit* hits_out) {

@@ -121,29 +121,39 @@ def gather_frame(local, vw, vh, rank, world, detile):
 
 
 class ShardedRenderer:
-    """One rank's view of a sharded render on the GPU: rt_render_shard + gather + rt_detile."""
+    """One rank's view of a sharded render on the GPU: rt_render_shard (or rt_render_shard_batch for `batch` frames
+    at once) + gather + rt_detile."""
 
-    def __init__(self, ctx, rank, world, device):
+    def __init__(self, ctx, rank, world, device, batch=1):
         import torch
-        self.ctx, self.rank, self.world, self.device = ctx, rank, world, device
+        self.ctx, self.rank, self.world, self.device, self.batch = ctx, rank, world, device, batch
         self.vw, self.vh = ctx.vw, ctx.vh
         self.slots = max_shard_slots(self.vw, self.vh, world)
-        self.local = torch.zeros(self.slots * 3, dtype=torch.uint8, device=device)
-        self.frame = torch.zeros(self.vh * self.vw * 3, dtype=torch.uint8, device=device) if rank == 0 else None
+        self.local = torch.zeros(batch * self.slots * 3, dtype=torch.uint8, device=device)
+        self.frame = torch.zeros(batch * self.vh * self.vw * 3, dtype=torch.uint8, device=device) if rank == 0 else None
 
     def render(self):
         """-> (RtStats of this rank, frame tensor on rank 0 / None)"""
-        import torch
         st = self.ctx.render_shard(self.rank, self.world, self.local.data_ptr())
         frame = gather_frame(self.local, self.vw, self.vh, self.rank, self.world, self.detile)
         return st, frame
+
+    def render_local(self, cameras=None):
+        """this rank's shard into self.local: one frame through the scene's own camera, or one frame per camera"""
+        if cameras is None:
+            return self.ctx.render_shard(self.rank, self.world, self.local.data_ptr())
+        assert len(cameras) <= self.batch
+        return self.ctx.render_shard_batch(self.rank, self.world, cameras, self.local.data_ptr())
 
     def detile(self, gathered):
         import torch
         # the gather runs on torch's stream, rt_detile on the context's own: join them here
         if torch.device(self.device).type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
-        self.ctx.detile(gathered.data_ptr(), self.world, self.slots, 3, self.frame.data_ptr())
+        if self.batch == 1:
+            self.ctx.detile(gathered.data_ptr(), self.world, self.slots, 3, self.frame.data_ptr())
+        else:
+            self.ctx.detile_frames(gathered.data_ptr(), self.world, self.batch, self.slots, 3, self.frame.data_ptr())
         return self.frame
 
 
@@ -151,19 +161,23 @@ class FramePipeline:
     """Several frames of a sequence in flight on one GPU (the reference's multi-frame workload is `--sequence`,
     sdl/src/main.rs:70-95: independent frames, one after the other).
 
-    A frame is a chain of dependent launches with a count read-back per level; near the end of each launch only a
-    few long rays are left and most of the chip idles.  With `depth` contexts, each driven by its own host thread
-    (the library calls release the GIL), the next frame's work fills those gaps.  Frames are handed back in order;
-    the gather to rank 0 and the de-tile run on the calling thread, in frame order on every rank, so the collective
-    sequence is the same everywhere.
+    A frame is a chain of dependent launches; near the end of each launch only a few long rays are left and most
+    of the chip idles.  With `depth` contexts, each driven by its own host thread (the library calls release the
+    GIL), the next frame's work fills those gaps.  Frames are handed back in order; the gather to rank 0 and the
+    de-tile run on the calling thread, in frame order on every rank, so the collective sequence is the same
+    everywhere.
+
+    batch > 1: a slot renders `batch` consecutive frames of a camera path in one set of launches
+    (rt_render_shard_batch) and they are gathered together.  The launches of a 1/N shard are N times smaller than a
+    whole frame's and fill the chip badly; batches of N frames restore their size.
     """
 
-    def __init__(self, make_context, rank, world, device, depth=2):
+    def __init__(self, make_context, rank, world, device, depth=2, batch=1):
         import queue
         import threading
-        self.rank, self.world, self.device, self.depth = rank, world, device, depth
+        self.rank, self.world, self.device, self.depth, self.batch = rank, world, device, depth, batch
         self.ctxs = [make_context() for _ in range(depth)]
-        self.renderers = [ShardedRenderer(c, rank, world, device) for c in self.ctxs]
+        self.renderers = [ShardedRenderer(c, rank, world, device, batch) for c in self.ctxs]
         self._go = [queue.Queue() for _ in range(depth)]
         self._done = [queue.Queue() for _ in range(depth)]
         self._threads = [threading.Thread(target=self._worker, args=(k,), daemon=True) for k in range(depth)]
@@ -177,28 +191,44 @@ class FramePipeline:
             if job is None:
                 return
             try:
-                self._done[k].put(r.ctx.render_shard(r.rank, r.world, r.local.data_ptr()))
+                self._done[k].put(r.render_local(job[1]))
             except Exception as e:  # handed to the caller of run()
                 self._done[k].put(e)
 
-    def run(self, n_frames, on_frame=None):
-        """Renders n_frames frames; on_frame(index, stats, frame_tensor_or_None) is called in frame order.
-        Returns the list of per-frame RtStats of this rank."""
+    def run(self, n_frames, on_frame=None, camera_of=None):
+        """Renders n_frames frames; on_frame(index, stats, frame_tensor_or_None) is called in frame order (stats: the
+        RtStats of the set of launches the frame was part of, with .frames = how many frames that set covered).
+        camera_of(f) -> Camera of frame f; required when batch > 1, optional otherwise (None: the scene's camera).
+        Returns the list of RtStats of this rank, one per set of launches."""
+        if self.batch > 1 and camera_of is None:
+            raise ValueError("a batched pipeline needs the frames' cameras (camera_of)")
+        B = self.batch
+        n_jobs = (n_frames + B - 1) // B
+
+        def job(j):
+            lo, hi = j * B, min((j + 1) * B, n_frames)
+            cams = None if camera_of is None else self.ctxs[j % self.depth].camera_array([camera_of(f) for f in range(lo, hi)])
+            return (j, cams)
+
         stats = []
-        for f in range(min(self.depth, n_frames)):
-            self._go[f % self.depth].put(f)
-        for f in range(n_frames):
-            k = f % self.depth
+        for j in range(min(self.depth, n_jobs)):
+            self._go[j % self.depth].put(job(j))
+        for j in range(n_jobs):
+            k = j % self.depth
             st = self._done[k].get()
             if isinstance(st, Exception):
                 raise st
             r = self.renderers[k]
-            frame = gather_frame(r.local, r.vw, r.vh, self.rank, self.world, r.detile)
+            lo, hi = j * B, min((j + 1) * B, n_frames)
+            st.frames = hi - lo
+            frames = gather_frame(r.local, r.vw, r.vh, self.rank, self.world, r.detile)
             if on_frame is not None:
-                on_frame(f, st, frame)
+                per = r.vw * r.vh * 3
+                for f in range(lo, hi):
+                    on_frame(f, st, None if frames is None else frames[(f - lo) * per:(f - lo + 1) * per])
             stats.append(st)
-            if f + self.depth < n_frames:
-                self._go[k].put(f + self.depth)     # the slot's buffer is free again once its frame is gathered
+            if j + self.depth < n_jobs:
+                self._go[k].put(job(j + self.depth))     # the slot's buffer is free again once its frames are gathered
         return stats
 
     def close(self):

@@ -250,5 +250,7 @@ Scene* rth_sdl_load(const char* source_or_path, int is_path, const char* base_di
 }
 const char* rth_sdl_printed() { return g_printed.c_str(); }
 void rth_scene_counts(Scene* s, uint32_t* out) { out[0] = (uint32_t)s->objects.size(); out[1] = (uint32_t)s->lights.size(); out[2] = (uint32_t)s->camera.vw; out[3] = (uint32_t)s->camera.vh; }
+// Camera::chf (camera.rs:45-47), for callers that fill an rt_camera themselves
+double rth_camera_chf(double fov) { return Camera::chf_of(fov); }
 
 }  // extern "C"

@@ -68,6 +68,33 @@ class Context:
                                             C.c_void_p(d_ids_ptr) if d_ids_ptr else None, C.byref(st)))
         return st
 
+    def camera_array(self, cameras):
+        """rt_camera array from Camera objects (camera.rs:5-27); every frame has the context's frame size"""
+        arr = (N.RtCamera * len(cameras))()
+        for a, cam in zip(arr, cameras):
+            a.vw, a.vh = self.vw, self.vh
+            a.origin = (C.c_double * 3)(*[float(x) for x in cam.origin])
+            a.yaw, a.pitch, a.fov = float(cam.yaw), float(cam.pitch), float(cam.fov)
+            a.chf = N.host().rth_camera_chf(float(cam.fov))
+        return arr
+
+    def render_shard_batch(self, shard, n_shards, cameras, d_rgb_ptr, d_ids_ptr=None, frame_stride=None):
+        """rt_render_shard_batch: this shard of len(cameras) frames that differ in their camera only, in one set of
+        launches; frame f's compact shard starts at slot f * frame_stride (default: the largest shard's size, shard
+        0's, which is what a gather across ranks needs).  `cameras`: Camera objects or a ready rt_camera array
+        (camera_array)."""
+        arr = cameras if isinstance(cameras, C.Array) else self.camera_array(cameras)
+        if frame_stride is None:
+            frame_stride = self.shard_pixels(0, n_shards)
+        st = N.RtStats()
+        self._check(N.gpu().rt_render_shard_batch(self._c, shard, n_shards, len(arr), arr, int(frame_stride), C.c_void_p(d_rgb_ptr),
+                                                  C.c_void_p(d_ids_ptr) if d_ids_ptr else None, C.byref(st)))
+        return st
+
+    def detile_frames(self, d_gathered_ptr, n_shards, n_frames, slots_per_shard, elem_bytes, d_images_ptr):
+        self._check(N.gpu().rt_detile_frames(self._c, C.c_void_p(d_gathered_ptr), n_shards, n_frames, slots_per_shard, elem_bytes,
+                                             C.c_void_p(d_images_ptr)))
+
     def detile(self, d_gathered_ptr, n_shards, slots_per_shard, elem_bytes, d_image_ptr):
         self._check(N.gpu().rt_detile(self._c, C.c_void_p(d_gathered_ptr), n_shards, slots_per_shard, elem_bytes, C.c_void_p(d_image_ptr)))
 

@@ -131,8 +131,88 @@ class _OracleCtx:
         out = rd.detile_host(g, self.vw, self.vh, world, slots, elem)
         ctypes.memmove(fptr, out.ctypes.data, out.nbytes)
 
+    # -- batches of frames that differ in their camera (rt_render_shard_batch / rt_detile_frames)
+    def camera_array(self, cameras):
+        return list(cameras)
+
+    def render_shard_batch(self, rank, world, cams, ptr):
+        import ctypes
+        import oracle
+        from raytracer_amd import dist as rd
+        from raytracer_amd import scenes
+        slots = rd.max_shard_slots(self.vw, self.vh, world)
+        idx = rd.shard_pixel_indices(self.vw, self.vh, rank, world)
+        ok = idx >= 0
+        local = np.zeros((len(cams), slots, 3), dtype=np.uint8)
+        st = None
+        for f, cam in enumerate(cams):
+            s = scenes.small_mixed_scene(self.vw, self.vh, cells=5)
+            cam.vw, cam.vh = self.vw, self.vh
+            s.set_camera(cam)
+            rgb, _, st, _ = oracle.render(s, 1, pixels=idx[ok].astype(np.uint32), ids=False)
+            local[f][: len(idx)][ok] = rgb
+        ctypes.memmove(ptr, local.ctypes.data, local.nbytes)
+        return st
+
+    def detile_frames(self, gptr, world, n_frames, slots, elem, fptr):
+        import ctypes
+        from raytracer_amd import dist as rd
+        g = np.ctypeslib.as_array((ctypes.c_uint8 * (world * n_frames * slots * elem)).from_address(gptr)).reshape(world, n_frames, slots, elem)
+        out = np.stack([rd.detile_host(np.ascontiguousarray(g[:, f]), self.vw, self.vh, world, slots, elem) for f in range(n_frames)])
+        ctypes.memmove(fptr, out.ctypes.data, out.nbytes)
+
     def close(self):
         pass
+
+
+def _path_camera(f):
+    from raytracer_amd.scene import Camera
+    return Camera(origin=(0.2 * f, 0.1 * f, 0.), yaw=0.04 * f, pitch=-0.02 * f)
+
+
+def _batch_worker(rank, world, port, vw, vh, n_frames, batch, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracer_amd import dist as rd
+        pipe = rd.FramePipeline(lambda: _OracleCtx(vw, vh), rank, world, torch.device("cpu"), depth=2, batch=batch)
+        frames, covered = [], []
+
+        def on_frame(f, st, frame):
+            covered.append(st.frames)
+            if rank == 0:
+                frames.append(frame.numpy().reshape(vh, vw, 3).copy())
+
+        stats = pipe.run(n_frames, on_frame, camera_of=_path_camera)
+        pipe.close()
+        assert len(stats) == -(-n_frames // batch) and len(covered) == n_frames
+        assert covered[-1] == (n_frames % batch or batch)
+        if rank == 0:
+            np.save(out_path, np.stack(frames))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_batched_pipeline_delivers_every_frame_of_a_camera_path(tmp_path):
+    """batches of 3 frames per set of launches, two batches in flight, world size 2, a last batch of one frame"""
+    sys.path.insert(0, ROOT)
+    import oracle
+    from raytracer_amd import scenes
+    vw, vh, n_frames = 36, 20, 7
+    port = 33500 + (os.getpid() % 2000)
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_batch_worker, args=(2, port, vw, vh, n_frames, 3, out), nprocs=2, join=True)
+    frames = np.load(out)
+    assert frames.shape[0] == n_frames
+    for f in range(n_frames):
+        s = scenes.small_mixed_scene(vw, vh, cells=5)
+        cam = _path_camera(f)
+        cam.vw, cam.vh = vw, vh
+        s.set_camera(cam)
+        full, _, _, _ = oracle.render(s, 1)
+        assert np.array_equal(frames[f], full), f
 
 
 def _pipeline_worker(rank, world, port, vw, vh, n_frames, out_path):

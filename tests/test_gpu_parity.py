@@ -518,3 +518,79 @@ def test_lopsided_tree_fills_the_packet_stack(gpu_ctx):
     with pytest.raises(N.RtError) as e:
         gpu_ctx.upload(scene_with(_spine_mesh(56)))
     assert e.value.code == N.RT_ERR_UNSUPPORTED and "stack" in str(e.value)
+
+
+def test_speculative_frames_equal_measured_ones_and_fall_back_when_a_level_outgrows_its_room(monkeypatch):
+    """A context queues every frame after its first without reading the level sizes back, giving each level the room
+    the previous frame's level needed plus a quarter.  Same frame either way; when the scene changes so much that a
+    level outgrows its room, the frame is rendered again the measured way."""
+    a = scenes.small_mixed_scene(160, 120, cells=10)
+    o_rgb, o_ids, o_st, _ = oracle.render(a, 0)
+    with ra.Context(0) as ctx:
+        ctx.upload(a)
+        r1, i1, s1 = ctx.render(ids=True)          # measured: nothing learned yet
+        r2, i2, s2 = ctx.render(ids=True)          # speculative
+        assert (s1.speculative, s2.speculative) == (0, 1) and s2.respeculated == 0
+        for r, i, s in ((r1, i1, s1), (r2, i2, s2)):
+            assert np.array_equal(r, o_rgb) and np.array_equal(i, o_ids)
+            assert ray_counts(s) == ray_counts(o_st) and list(s.rays_per_level) == list(o_st.rays_per_level)
+        # same size, far fewer secondary rays, then far more: the second change overflows the learned room
+        few = ra.Scene()
+        few.set_camera(ra.Camera(vw=160, vh=120))
+        few.add(ra.Sphere((0., 0., -5.), 0.5, ra.Material(reflectiveness=0.3)))
+        few.add_light(ra.Sun())
+        ctx.upload(few)
+        rf, _, sf = ctx.render()
+        assert np.array_equal(rf, oracle.render(few, 0)[0]) and sf.respeculated == 0
+        ctx.upload(a)
+        r3, i3, s3 = ctx.render(ids=True)
+        assert s3.respeculated == 1 and s3.speculative == 0
+        assert np.array_equal(r3, o_rgb) and np.array_equal(i3, o_ids) and ray_counts(s3) == ray_counts(o_st)
+        r4, _, s4 = ctx.render()
+        assert s4.speculative == 1 and s4.respeculated == 1 and np.array_equal(r4, o_rgb)
+    monkeypatch.setenv("RTGPU_SYNC_LEVELS", "1")
+    with ra.Context(0) as ctx:
+        ctx.upload(a)
+        for _ in range(2):
+            r, i, s = ctx.render(ids=True)
+            assert s.speculative == 0 and np.array_equal(r, o_rgb) and np.array_equal(i, o_ids)
+
+
+def test_batched_shards_of_a_camera_path_equal_the_frames_rendered_one_by_one():
+    """rt_render_shard_batch: one set of launches for the same shard of several frames that differ in their camera;
+    rt_detile_frames puts the gathered batches back together.  Every frame equals its own rt_render."""
+    import torch
+    vw, vh, n_shards, n_frames = 200, 120, 3, 4
+    cams = [ra.Camera(vw=vw, vh=vh, origin=(0.3 * f, 2.0 + 0.2 * f, 6.0), yaw=0.05 * f, pitch=-0.35 + 0.03 * f, fov=60. - 4 * f) for f in range(n_frames)]
+    s = scenes.small_mixed_scene(vw, vh, cells=10)
+    want, want_rays = [], 0
+    with ra.Context(0) as ctx:
+        for cam in cams:
+            s.set_camera(cam)
+            ctx.upload(s)
+            rgb, _, st = ctx.render()
+            want.append(rgb)
+            want_rays += st.rays
+        assert not np.array_equal(want[0], want[1])
+        s.set_camera(cams[0])
+        ctx.upload(s)
+        slots = rd.max_shard_slots(vw, vh, n_shards)
+        gathered = torch.zeros(n_shards * n_frames * slots * 3, dtype=torch.uint8, device="cuda")
+        rays = 0
+        for k in range(n_shards):
+            for rep in range(2):        # second time: queued without reading level sizes back
+                st = ctx.render_shard_batch(k, n_shards, cams, gathered.data_ptr() + k * n_frames * slots * 3)
+            assert st.speculative == 1
+            rays += st.rays
+        frames = torch.zeros(n_frames * vh * vw * 3, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.detile_frames(gathered.data_ptr(), n_shards, n_frames, slots, 3, frames.data_ptr())
+        got = frames.cpu().numpy().reshape(n_frames, vh, vw, 3)
+        for f in range(n_frames):
+            assert np.array_equal(got[f], want[f]), f
+        assert rays == want_rays
+        # frame size mismatch and bad counts are refused
+        bad = ctx.camera_array(cams[:1]); bad[0].vw = vw + 1
+        with pytest.raises(N.RtError) as e:
+            ctx.render_shard_batch(0, n_shards, bad, gathered.data_ptr())
+        assert e.value.code == N.RT_ERR_INVALID

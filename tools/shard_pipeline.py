@@ -14,18 +14,23 @@ from raytracer_amd import dist as rd, scenes  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 shard = int(os.environ.get("SHARD", "0"))     # which of the n shards
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+batch = int(os.environ.get("BATCH", "1"))      # frames per set of launches (rt_render_shard_batch)
 s = scenes.synthetic_terrain_scene(3840, 2160)
 for depth in [int(x) for x in os.environ.get("DEPTHS", "1,2,3,4").split(",")]:
     ctxs = [ra.Context(0) for _ in range(depth)]
     for c in ctxs:
         c.upload(s)
-    bufs = [torch.zeros(rd.max_shard_slots(3840, 2160, n) * 3, dtype=torch.uint8, device="cuda:0") for _ in range(depth)]
+    bufs = [torch.zeros(batch * rd.max_shard_slots(3840, 2160, n) * 3, dtype=torch.uint8, device="cuda:0") for _ in range(depth)]
+    cams = ctxs[0].camera_array([s.camera] * batch)
 
     last = [None]
 
     def work(k, count):
         for _ in range(count):
-            last[0] = ctxs[k].render_shard(shard, n, bufs[k].data_ptr())
+            if batch > 1:
+                last[0] = ctxs[k].render_shard_batch(shard, n, cams, bufs[k].data_ptr())
+            else:
+                last[0] = ctxs[k].render_shard(shard, n, bufs[k].data_ptr())
 
     for k in range(depth):
         work(k, 2)
@@ -37,7 +42,7 @@ for depth in [int(x) for x in os.environ.get("DEPTHS", "1,2,3,4").split(",")]:
     for t in ts:
         t.join()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) * 1e3 / (frames * depth)
-    print(f"shard {shard} of {n}, {depth} in flight: {dt:.3f} ms per frame, {last[0].rays} rays", flush=True)
+    dt = (time.perf_counter() - t0) * 1e3 / (frames * depth * batch)
+    print(f"shard {shard} of {n}, {depth} x {batch} in flight: {dt:.3f} ms per frame, {last[0].rays // batch} rays per frame", flush=True)
     for c in ctxs:
         c.close()
