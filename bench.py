@@ -10,9 +10,17 @@ One step = one frame: every rank renders its interleaved 16x16 tiles (rt_render_
 gathered to rank 0 (RCCL) and scattered into the row-major frame (rt_detile).  The scene is resident in HBM before the
 timed region; the frame stays in HBM.  A ray is one Scene::cast_ray_once call of the reference.
 
-The K timed frames are a sequence (the reference's --sequence workload): --frames-in-flight F (default 4; 8 when the frame is sharded) of them are
-in flight per GPU, each complete and delivered in order; F = 1 renders them strictly one after the other.  The line
-also carries the one-frame-at-a-time figure (`ms_per_frame_alone`).
+The K timed frames are a sequence (the reference's --sequence workload): --frames-in-flight F sets of launches (default
+4 on one GPU, 2 when the frame is sharded) are in flight per GPU, each frame complete and delivered in order; F = 1
+renders them strictly one after the other.  When the frame is sharded over N GPUs a set of launches covers this rank's
+shard of --batch B = N consecutive frames (rt_render_shard_batch), which keeps the launches as large as a whole
+frame's.  The line also carries the one-frame-at-a-time figure (`ms_per_frame_alone`) and, on one GPU, the time per
+frame through rt_render, host pixels included (`ms_per_frame_end_to_end`).
+
+Roofline of the dominant kernel (the budget-free shadow packet kernel, k_shadow<false, false>): its launches are timed
+alone (a context whose kernels run one after the other, HIP events around the kernel on its own stream); numerators
+are work the kernel really does -- BVH bytes its walks fetch (instrumented variant), HBM-side bytes and VALU-busy
+cycles from the rocprofv3 counter passes kept under profiles/ -- and `bound` is the roof it comes closest to.
 """
 import argparse
 import json
@@ -22,23 +30,19 @@ import time
 
 import numpy as np
 
-# One HIP stream per concurrent chain of launches: a frame uses five (trace/spawn + four shadow/light chains) and
-# several frames are in flight.  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (its
-# default, 4, is also what the environment of a GPU box usually holds); streams that share a queue run one after the
-# other.  A whole frame's launches fill the chip on their own and 4 queues serve it as well as any number (1 % better
-# than 24, in fact).  The launches of a 1/N shard are N times shorter and only fill the chip when the chains of the
-# frames in flight really overlap: a 1/8 shard takes 2.2 ms with 4 queues and 1.6 ms with 24 (four frames in flight
-# are 20 streams, plus torch's and RCCL's own).  So a multi-GPU run asks for 24; RT_HW_QUEUES overrides either way.
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue
+# run one after the other.  Whole frames, and batches of N shards of 1/N frame, fill the chip with the default; the
+# variable is left alone unless RT_HW_QUEUES asks for an experiment.
 if os.environ.get("RT_HW_QUEUES"):
     os.environ["GPU_MAX_HW_QUEUES"] = os.environ["RT_HW_QUEUES"]
-elif int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    os.environ["GPU_MAX_HW_QUEUES"] = "24"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, spec
+SIMDS = 256 * 4         # compute units x SIMDs
+CLOCK_GHZ = 2.4         # peak engine clock, spec
 
 
 def cpu_leg(scene, vw, vh, seconds, cores, frame_rgb):
@@ -83,6 +87,7 @@ def main():
     ap.add_argument("--lights", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--frames-in-flight", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="frames per set of launches (default: 1 on one GPU, N on N GPUs)")
     args = ap.parse_args()
 
     import torch
@@ -125,17 +130,18 @@ def main():
         t_upload[0] = time.perf_counter() - t0
         return c
 
+    # One GPU, whole frame: 4 frames in flight.  A 1/N shard's launches are N times smaller and fill the chip badly
+    # (a 1/8 shard takes 1.7-2.4 ms per frame however many are in flight, against 1.35 for an eighth of a whole frame);
+    # N consecutive frames per set of launches restore their size, and two such sets in flight hide the tails.
+    if args.batch is None:
+        args.batch = 1 if world == 1 else min(world, 8)
     if args.frames_in_flight is None:
-        # One GPU, whole frame: 4 frames in flight, each with four shadow/light chains of its own.  A shard's launches are
-        # short, and what fills the chip then is more frames rather than more chains per frame: 8 frames with one
-        # shadow/light chain each (16 streams) render a 1/8 shard 2 % faster, halves and quarters equally fast.
-        args.frames_in_flight = 4 if world == 1 else 8
-        if world > 1:
-            os.environ.setdefault("RTGPU_SIDE_STREAMS", "1")
-    depth = max(1, args.frames_in_flight)
-    pipe = rd.FramePipeline(make_context, rank, world, device, depth=depth)
+        args.frames_in_flight = 4 if args.batch == 1 else 2
+    depth, batch = max(1, args.frames_in_flight), max(1, args.batch)
+    pipe = rd.FramePipeline(make_context, rank, world, device, depth=depth, batch=batch)
     t_upload = t_upload[0]
     info = ra.desc_info(scene.flatten())
+    camera_of = (lambda f: scene.camera) if batch > 1 else None     # the sequence: the same view, frame after frame
 
     def sync():
         torch.cuda.synchronize(device)
@@ -149,29 +155,37 @@ def main():
     def keep(f, st, frame):
         last["st"], last["frame"] = st, frame
 
-    pipe.run(max(args.warmup, depth), keep)
+    def run(n, cb=keep):
+        return pipe.run(n, cb, camera_of=camera_of)
+
+    # warm-up: every context renders, and every shape of launch set the timed run will use (a last, shorter batch
+    # included) has been seen once, so that its level sizes are known (see rt_stats.speculative)
+    run(max(args.warmup, depth * batch))
+    if batch > 1:
+        run(args.steps)
+    run(1)
     sync()
     t0 = time.perf_counter()
     alone = 3
     for _ in range(alone):
-        pipe.run(1, keep)
+        run(1)
     sync()
     ms_alone = (time.perf_counter() - t0) * 1e3 / alone
 
-    pipe.run(args.warmup, keep)
+    run(args.warmup)
     sync()
     t0 = time.perf_counter()
-    stats = pipe.run(args.steps, keep)
+    stats = run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     st, frame = last["st"], last["frame"]
     ms_trace = sum(x.ms_trace for x in stats); ms_shadow = sum(x.ms_shadow for x in stats)
     ms_shade = sum(x.ms_shade for x in stats); ms_resolve = sum(x.ms_resolve for x in stats)
     ms_kernels = sum(x.ms_render for x in stats)
-    launches = {"k_trace": sum(x.launches_trace for x in stats), "k_shadow": sum(x.launches_shadow for x in stats),
-                "k_spawn": sum(x.launches_shade for x in stats)}
+    n_respeculated = int(stats[-1].respeculated)
 
-    rays = torch.tensor([st.rays_primary, st.rays_reflect, st.rays_transmit, st.rays_shadow], dtype=torch.int64, device=device)
+    per = float(st.frames)
+    rays = torch.tensor([round(v / per) for v in (st.rays_primary, st.rays_reflect, st.rays_transmit, st.rays_shadow)], dtype=torch.int64, device=device)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -182,61 +196,107 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = rays_frame * args.steps / elapsed / 1e6
 
-    visits = None
+    # ---- untimed legs on rank 0 of a one-GPU run: end-to-end frames, exclusive kernel durations, instrumented counts
+    visits = end_to_end = serial = None
     if rank == 0 and world == 1:
-        # what the GPU traversal really touched: one untimed frame through the instrumented kernel variants
-        os.environ["RTGPU_COUNT_VISITS"] = "1"
+        # (1) Scene::render's own contract: pixels in host memory (scene.rs:220-246) -- rt_render, one frame at a time
+        ctx0 = pipe.ctxs[0]
+        ctx0.render()
+        t0 = time.perf_counter()
+        n_e2e = 5
+        for _ in range(n_e2e):
+            ctx0.render()
+        end_to_end = (time.perf_counter() - t0) * 1e3 / n_e2e
         pipe.close()
         pipe = None
-        cctx = ra.Context(local_rank)
-        cctx.upload(scene)
-        _, _, cst = cctx.render(ids=False)
-        cctx.close()
-        del os.environ["RTGPU_COUNT_VISITS"]
+        # (2) the dominant kernel alone: a context whose kernels run one after the other on one stream, so that the
+        #     HIP events around k_shadow<false, false> (on that stream) bracket nothing else
+        os.environ["RTGPU_SERIAL"] = "1"
+        sctx = ra.Context(local_rank)
+        sctx.upload(scene)
+        sctx.render()
+        sst = [sctx.render()[2] for _ in range(4)]
+        sctx.close()
+        del os.environ["RTGPU_SERIAL"]
+        n_main = sum(x.launches_shadow_main for x in sst)
+        serial = {"frames": len(sst), "ms_per_frame_kernels": sum(x.ms_render for x in sst) / len(sst),
+                  "k_shadow_main_launches_per_frame": n_main / len(sst),
+                  "k_shadow_main_avg_launch_ms": sum(x.ms_shadow_main for x in sst) / max(n_main, 1),
+                  "ms_per_frame": {"trace": sum(x.ms_trace for x in sst) / len(sst), "shadow": sum(x.ms_shadow for x in sst) / len(sst),
+                                   "spawn+light": sum(x.ms_shade for x in sst) / len(sst), "resolve": sum(x.ms_resolve for x in sst) / len(sst)}}
+        # (3) what the traversal really touched: one frame through the instrumented kernel variants (all kernels), and
+        #     one with only the shadow kernels instrumented (the bytes of the dominant kernel's launches)
+        def instrumented(which):
+            os.environ["RTGPU_COUNT_VISITS"] = which
+            cctx = ra.Context(local_rank)
+            cctx.upload(scene)
+            _, _, cst = cctx.render(ids=False)
+            cctx.close()
+            del os.environ["RTGPU_COUNT_VISITS"]
+            return cst
+        cst, shst = instrumented("1"), instrumented("shadow")
         visits = {"lane_node_visits": int(cst.nodes_visited), "lane_tri_tests": int(cst.tris_tested),
                   # wave_tri_steps: triangle records fetched per wave by the closest-hit packets, and rounds of 64
                   # (ray, leaf) pairs tested by the shadow packets (whose lanes fetch their own triangles)
                   "wave_node_fetches": int(cst.wave_nodes), "wave_tri_steps": int(cst.wave_tris),
                   # B_touched: node and triangle records the walks really fetched, at their real sizes (112 / 80
                   # bytes), a packet's shared fetch counted once
-                  "bytes_touched": int(cst.bytes_fetched)}
+                  "bytes_touched": int(cst.bytes_fetched),
+                  "bytes_touched_k_shadow_main": int(shst.bytes_fetched_main), "k_shadow_main_launches": int(shst.launches_shadow_main)}
 
     if rank == 0:
         frame_rgb = frame.cpu().numpy().reshape(vh, vw, 3)
         cores = int(os.environ.get("OMP_NUM_THREADS") or min(os.cpu_count() or 1, 16))
-        # N == 1: the timed CPU baseline.  N > 1: only a short counting pass for the roofline numerator.
+        # N == 1: the timed CPU baseline.  N > 1: only a short pass for the parity figure.
         cpu = cpu_leg(scene, vw, vh, args.cpu_seconds if world == 1 else 3.0, cores, frame_rgb)
 
-        # Roofline of the dominant kernel.  Algorithmic bytes are counted under the reference's exhaustive semantics
-        # (32 B per BVH node test, 36 per triangle, 16/28/24 per sphere/plane/box, 3 per texel) on the sampled pixels
-        # and scaled to the frame: k_trace owns the closest-hit casts, k_shadow the shadow casts, k_shade the
-        # refraction helper intersects and the texel fetches.  With N ranks each launch handles 1/N of the frame;
-        # a frame launches each kernel once per trace_ray depth that has rays.
-        per_kernel = {"k_trace": (cpu["bytes_closest"], ms_trace), "k_shadow": (cpu["bytes_shadow"], ms_shadow),
-                      "k_spawn": (cpu["bytes_helper"] + cpu["bytes_texels"], ms_shade)}
-        kernels = {}
-        for name, (bytes_frame, ms) in per_kernel.items():
-            n_l = max(launches[name], 1)
-            avg_ms = ms / n_l
-            bytes_launch = bytes_frame / world / (n_l / max(args.steps, 1))
-            gbs = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            kernels[name] = {"avg_launch_ms": avg_ms, "launches_per_frame": n_l / max(args.steps, 1), "bytes_per_launch": bytes_launch,
-                             "GB/s": gbs, "ms_per_frame": ms / max(args.steps, 1)}
-        # The dominant kernel: the one that owns most of the frame's algorithmic bytes (the shadow casts: 8 per lit hit).
-        # Launch durations cannot decide it: the launches of different kernels overlap (side streams, frames in flight),
-        # each stretches by what it waits for the others, and the order of two sums flips from run to run.  With the
-        # kernels of a frame run one after the other (RTGPU_SERIAL=1, tools/prof_frame.py) it is the same kernel: 60 %
-        # of the frame's kernel time.
-        dom = max(per_kernel, key=lambda k: per_kernel[k][0])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("kernel") == dom and tj.get("n_gpus") == world and tj.get("workload_cells") == args.cells:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # B_alg, the survey's per-frame figure: bytes the REFERENCE's exhaustive walk would read (32 B per BVH node
+        # test, 36 per triangle, 16/28/24 per sphere/plane/box, 3 per texel), counted by the CPU port on the sampled
+        # pixels and scaled to the frame.  A side figure: the device walk prunes by distance and ends a shadow cast at
+        # the first blocker, so it does not do that work, and B_alg over time is not a fraction of any roof.
+        b_alg = {"closest_casts": cpu["bytes_closest"], "shadow_casts": cpu["bytes_shadow"],
+                 "helper_intersects_and_texels": cpu["bytes_helper"] + cpu["bytes_texels"]}
+        b_alg["total"] = sum(b_alg.values())
+        b_alg["GB/s_over_frame_time"] = b_alg["total"] / (ms_per_step * 1e-3) / 1e9
+
+        roofline = None
+        if serial and serial["k_shadow_main_avg_launch_ms"] > 0:
+            dur = serial["k_shadow_main_avg_launch_ms"] * 1e-3          # exclusive, measured in this run
+            n_l = serial["k_shadow_main_launches_per_frame"]
+            fr = {}
+            touched = visits["bytes_touched_k_shadow_main"] / max(visits["k_shadow_main_launches"], 1)
+            fr["bvh_bytes_touched"] = {"achieved": touched / dur / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_launch": touched,
+                                       "note": "node and triangle records the launch's walks fetch (mostly served by the caches)"}
+            fr["bvh_bytes_touched"]["frac"] = fr["bvh_bytes_touched"]["achieved"] / HBM_PEAK_GBS
+            traffic = None
+            ipath = os.path.join(ROOT, "profiles", "r2_roofline_inputs.json")
+            if os.path.exists(ipath):
+                try:
+                    inp = json.load(open(ipath))
+                    if inp.get("workload_cells") == args.cells and inp.get("resolution") == [vw, vh] and inp.get("lights") == args.lights:
+                        k = inp["k_shadow_main"]
+                        traffic = k["hbm_bytes_per_launch"]
+                        fr["hbm"] = {"achieved": traffic / dur / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_launch": traffic,
+                                     "note": "(2 x FETCH_SIZE + WRITE_SIZE) of the counter passes in profiles/, per launch"}
+                        fr["hbm"]["frac"] = fr["hbm"]["achieved"] / HBM_PEAK_GBS
+                        busy = k["valu_busy_cycles_per_launch"]         # SQ_ACTIVE_INST_VALU x 4, summed over the chip's SIMDs
+                        peak = SIMDS * CLOCK_GHZ
+                        fr["valu"] = {"achieved": busy / dur / 1e9, "peak": peak, "unit": "G SIMD-cycles/s", "per_launch": busy,
+                                      "valu_instructions_per_launch": k.get("valu_insts_per_launch"),
+                                      "busy_at_measured_clock": k.get("valu_busy_frac_measured_clock"),
+                                      "note": "cycles the vector ALUs are busy (SQ_ACTIVE_INST_VALU x 4) against SIMDs x the 2.4 GHz "
+                                              "spec clock; the clock under this load is lower (busy_at_measured_clock uses GRBM_GUI_ACTIVE)"}
+                        fr["valu"]["frac"] = fr["valu"]["achieved"] / peak
+                except Exception as e:   # a malformed file must not lose the run
+                    fr["inputs_error"] = repr(e)
+            bound = max((k for k in fr if isinstance(fr[k], dict)), key=lambda k: fr[k]["frac"])
+            roofline = {"bound": bound, "kernel": "k_shadow<false, false>", "achieved": fr[bound]["achieved"], "peak": fr[bound]["peak"],
+                        "unit": fr[bound]["unit"], "frac": fr[bound]["frac"], "traffic": traffic,
+                        "avg_launch_ms": serial["k_shadow_main_avg_launch_ms"], "launches_per_frame": n_l,
+                        "share_of_frame_kernel_time": serial["k_shadow_main_avg_launch_ms"] * n_l / serial["ms_per_frame_kernels"],
+                        "roofs": fr,
+                        "note": "launch duration: HIP events around the kernel on its own stream in a context whose kernels run one "
+                                "after the other (this run); bound = the roof with the largest fraction"}
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -246,21 +306,19 @@ def main():
                             f"{args.lights} point lights with shadows, {vw}x{vh}, max_ray_depth 4 (BASELINE config 4)",
                 "resolution": [vw, vh], "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "lights": args.lights,
                 "parallelism": f"64x64-pixel supertiles interleaved over {world} GPU(s), gather to rank 0",
-                "frames_in_flight": depth,
+                "sets_of_launches_in_flight": depth, "frames_per_set_of_launches": batch,
             },
             "rays_per_frame": {"primary": rays[0], "reflect": rays[1], "transmit": rays[2], "shadow": rays[3], "total": rays_frame},
             "ms_per_frame_alone": ms_alone,
+            "ms_per_frame_end_to_end": end_to_end,
             "ms_per_frame_kernels_rank0": ms_kernels / args.steps,
             # sums of the launches' own durations; the phases (and frames) overlap, so they exceed the frame time
             "ms_phase_rank0": {"trace": ms_trace / args.steps, "shadow": ms_shadow / args.steps, "spawn+light": ms_shade / args.steps,
                                "resolve": ms_resolve / args.steps},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kernels[dom]["GB/s"] / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": kernels[dom]["avg_launch_ms"], "algorithmic_bytes_per_launch": kernels[dom]["bytes_per_launch"],
-                         "kernels": kernels,
-                         "note": "achieved = bytes the reference's exhaustive walk would read for this launch's casts / launch time; "
-                                 "the GPU walk prunes by distance and stops shadow casts at the first blocker, so it reads far less "
-                                 "(gpu_visits) and the figure can exceed the HBM peak; the kernel is bound by instruction issue (profiles/)"},
+            "frames_rendered_twice": n_respeculated,
+            "roofline": roofline,
+            "kernels_one_after_the_other": serial,
+            "reference_walk_bytes_per_frame": b_alg,
             "gpu_visits_per_frame": visits,
             "parity_vs_cpu_sample": cpu["parity"],
             "setup_s": {"scene_build": t_build, "upload": t_upload}, "device_bytes": int(st.device_bytes),
