@@ -137,9 +137,12 @@ struct DScene {
 // trace_ray depth (scene.rs:85) across the frame.
 struct DLevel {
     double* ro[3]; double* rd[3];                 // the ray
-    uint32_t* hit_obj; uint32_t* hit_prim;        // closest hit: object, triangle (leaf order)
-    double* hit_t; double* hit_t2;                // mesh hits: near / far t
-    float* hit_u; float* hit_v;                   // mesh hits: barycentrics (f32, mesh.rs:53-54)
+    // closest hit, as k_trace leaves it: the Hit of object/mod.rs:18-36 minus the two points (vnear = o + d * near and
+    // vfar = o + d * far are recomputed where needed: one multiply-add per component, the reference's own expression)
+    uint32_t* hit_obj; uint32_t* hit_prim;        // object; triangle in the mesh's own order (RT_NONE for other objects)
+    double* hit_t; double* hit_t2;                // Hit::near, Hit::far
+    float* hit_u; float* hit_v;                   // Hit::uv
+    double* nrm[3];                               // Hit::normal
     double* lit[3];                               // lit colour before the child mixes (scene.rs:122)
     double* w_t; double* w_r; double* emis;       // mix weights
     uint32_t* child0; uint32_t* child1;           // index in the next level (transmission, reflection)

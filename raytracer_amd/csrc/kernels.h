@@ -151,25 +151,29 @@ DEV DShard* my_shard(DCounters* C) { return &C->shard[(blockIdx.x + blockIdx.y *
 #define RT_LONG_BLOCKS 512     /* grid of the long-ray kernels (they loop over the list) */
 struct LongParams { uint32_t budget_lane, budget_wave; };
 
-// what k_trace does with the closest hit of ray i: the hit record, and the entry of the shadow work list
-// (hit point and the offset origin vnear + normal * EPSILON of sun.rs:88, point.rs:90) when the hit will be lit
+// what k_trace does with the closest hit of ray i: the full Hit record (normal, uv and far built ONCE here, for k_spawn
+// and k_light to read back in coalesced loads instead of each fetching the triangle's indices, normals and texture
+// coordinates again), and the entry of the shadow work list (hit point and the offset origin vnear + normal * EPSILON
+// of sun.rs:88, point.rs:90) when the hit will be lit
 template <bool MESHES = true>
 DEV void trace_finish(const DScene& S, DLevel& L, uint32_t i, bool active, const Ray& ray, bool hit, const Closest& c,
                       uint32_t* hitlist, double* hs, uint32_t stride, DLevelCounts* LC) {
     bool lit = false;
     D3 vnear = d3(0., 0., 0.), so = d3(0., 0., 0.);
-    if (active) {
-        L.hit_obj[i] = c.obj; L.hit_prim[i] = c.rank;
-        L.hit_t[i] = c.t; L.hit_t2[i] = c.t2; L.hit_u[i] = c.u; L.hit_v[i] = c.v;
-    }
-    if (active && hit && S.n_lights != 0) {
-        const RT_GLOBAL DObject* op = gptr(S.objects) + c.obj;
-        if (!(gptr(S.materials)[op->material].emissivity == 1.)) {      // scene.rs:105-107: fully emissive = no lighting
-            Hit h;
-            closest_hit_fill<MESHES>(S, ray, c.obj, c.rank, c.t, c.t2, c.u, c.v, h);
-            vnear = h.vnear;
-            so = h.vnear + h.normal * RT_EPSILON;
-            lit = true;
+    if (active) L.hit_obj[i] = c.obj;
+    if (active && hit) {
+        Hit h;
+        closest_hit_fill<MESHES>(S, ray, c.obj, c.rank, c.t, c.t2, c.u, c.v, h);
+        L.hit_prim[i] = h.prim;
+        L.hit_t[i] = h.near; L.hit_t2[i] = h.far; L.hit_u[i] = h.u; L.hit_v[i] = h.v;
+        L.nrm[0][i] = h.normal.x; L.nrm[1][i] = h.normal.y; L.nrm[2][i] = h.normal.z;
+        if (S.n_lights != 0) {
+            const RT_GLOBAL DObject* op = gptr(S.objects) + c.obj;
+            if (!(gptr(S.materials)[op->material].emissivity == 1.)) {      // scene.rs:105-107: fully emissive = no lighting
+                vnear = h.vnear;
+                so = h.vnear + h.normal * RT_EPSILON;
+                lit = true;
+            }
         }
     }
     const uint32_t slot = block_append(lit, &LC->hit_count);
@@ -178,6 +182,15 @@ DEV void trace_finish(const DScene& S, DLevel& L, uint32_t i, bool active, const
         hs[slot] = vnear.x; hs[(size_t)stride + slot] = vnear.y; hs[2 * (size_t)stride + slot] = vnear.z;
         hs[3 * (size_t)stride + slot] = so.x; hs[4 * (size_t)stride + slot] = so.y; hs[5 * (size_t)stride + slot] = so.z;
     }
+}
+
+// The Hit of ray i as trace_finish stored it (object/mod.rs:18-36)
+DEV void load_hit(const DLevel& L, uint32_t i, const Ray& ray, Hit& h) {
+    h.normal = d3(L.nrm[0][i], L.nrm[1][i], L.nrm[2][i]);
+    h.near = L.hit_t[i]; h.far = L.hit_t2[i];
+    h.vnear = along(ray, h.near); h.vfar = along(ray, h.far);
+    h.u = L.hit_u[i]; h.v = L.hit_v[i];
+    h.prim = L.hit_prim[i];
 }
 
 // Closest hit of every ray of the level.  Rays whose hit will be lit are appended (in wave order) to the work list
@@ -422,7 +435,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_spawn(const DScene* Sp, DLevel L, 
             if (ids_out && depth == 0) { ids_out[2 * io] = RT_NONE; ids_out[2 * io + 1] = RT_NONE; }
         } else {
             Hit hit;
-            closest_hit_fill(S, ray, obj, L.hit_prim[i], L.hit_t[i], L.hit_t2[i], L.hit_u[i], L.hit_v[i], hit);
+            load_hit(L, i, ray, hit);
             if (ids_out && depth == 0) { ids_out[2 * io] = obj; ids_out[2 * io + 1] = hit.prim; }
             const DMaterial& mat = S.materials[S.objects[obj].material];
             const uint32_t base_rgb = texture_at(mat, hit.u, hit.v);       // scene.rs:102
@@ -504,7 +517,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_light(const DScene* Sp, DLevel L, 
     const uint32_t obj = L.hit_obj[i];
     Ray ray = load_ray(L, i);
     Hit hit;
-    closest_hit_fill(S, ray, obj, L.hit_prim[i], L.hit_t[i], L.hit_t2[i], L.hit_u[i], L.hit_v[i], hit);
+    load_hit(L, i, ray, hit);
     const uint32_t base_rgb = bf & 0xFFFFFFu;
     D3 color = to_d3(base_rgb);
     D3 sum = ld3(S.ambient);                                   // scene.rs:110-120

@@ -404,9 +404,9 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
 }
 
 size_t level_bytes(size_t cap) {
-    // 6+2+3+3 doubles, 2 floats, 6 u32 per slot; each array padded to 256 B
+    // 6+2+3+3+3 doubles, 2 floats, 6 u32 per slot; each array padded to 256 B
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return 14 * pad(cap * 8) + 2 * pad(cap * 4) + 6 * pad(cap * 4);
+    return 17 * pad(cap * 8) + 2 * pad(cap * 4) + 6 * pad(cap * 4);
 }
 
 int ensure_level(rt_ctx* c, size_t idx, size_t cap) {
@@ -427,6 +427,7 @@ int ensure_level(rt_ctx* c, size_t idx, size_t cap) {
     for (int k = 0; k < 3; k++) L.ro[k] = takeD();
     for (int k = 0; k < 3; k++) L.rd[k] = takeD();
     L.hit_t = takeD(); L.hit_t2 = takeD();
+    for (int k = 0; k < 3; k++) L.nrm[k] = takeD();
     for (int k = 0; k < 3; k++) L.lit[k] = takeD();
     L.w_t = takeD(); L.w_r = takeD(); L.emis = takeD();
     L.hit_u = takeF(); L.hit_v = takeF();
