@@ -280,3 +280,71 @@ def spheres_over_terrain_scene(vw=192, vh=108, n=4, cells=24, seed=3):
                     s.add(Sphere(pos, 0.45, sdl_material(Texture.solid(col), reflectiveness=0.4,
                                                          transparency=0.5 if (i + k) % 3 == 0 else 0.)))
     return s
+
+
+# The cube of images/readme/10_7_2021.png, fitted (tools/fit_readme_10_7.py): the listing draws it from random()
+README_10_7_BOX = (0.7830276489257812, 0.9763870239257812, -7.986015319824219)
+
+
+def readme_10_7_scene(box_position=README_10_7_BOX, texture_pixels=None, vw=1920, vh=1080, point_intensity=2.):
+    """The test scene of the reference's progress log, README.md:172-247 = scenes/uwl_cube.sdl (rendered there as
+    images/readme/10_7_2021.png): a textured cube, a mirror sphere, a plain sphere, a wall, a checkered ground plate, one
+    sun and one reddish point light, default (Normal) skybox.  The cube's position is `random(-1, 1), random(0, 1),
+    random(-9, -7)` in the listing, so it is a parameter here.  texture_pixels: assets/uwl.png as RGB."""
+    s = Scene()
+    s.set_camera(Camera(vw=vw, vh=vh, fov=60., origin=(-3., 3., 0.), pitch=-0.5, yaw=0.4))
+    s.add_light(sdl_sun((-0.8, -1., -0.3), intensity=0.8, specular_power=64))
+    s.add(Aabb(tuple(box_position), (1., 1., 1.), sdl_material(Texture.image(texture_pixels))))
+    grey = Texture.solid((200, 200, 200))
+    s.add(Sphere((2.5, 0., -5.), 1., sdl_material(grey, reflectiveness=0.7)))
+    s.add(Sphere((-2.5, 0., -5.), 1., sdl_material(grey)))
+    s.add(Aabb((0., 2., -12.), (10., 3., 1.), sdl_material()))
+    s.add(sdl_plane((0., -1., 0.), material=sdl_material(Texture.checkerboard((128, 128, 128), (255, 255, 255)))))
+    s.add_light(Point(position=(0., 0., -3.5), color=(255, 100, 100), intensity=point_intensity))
+    return s
+
+
+def icosphere_soup(order):
+    """The generator of scenes/icosahedron.sdl: an icosahedron whose triangles are split in four `order` times
+    (midpoints are never shared between neighbours), every vertex pushed onto the unit sphere at the end, emitted as a
+    triangle soup in the script's order -- (3 * n_triangles, 3) positions."""
+    f = (1 + 5 ** 0.5) / 2
+    vertices = [float(x) for x in (-1, f, 0, 1, f, 0, -1, 0 - f, 0, 1, 0 - f, 0, 0, -1, f, 0, 1, f, 0, -1, 0 - f, 0, 1, 0 - f,
+                                   f, 0, -1, f, 0, 1, 0 - f, 0, -1, 0 - f, 0, 1)]
+    triangles = [0, 11, 5, 0, 5, 1, 0, 1, 7, 0, 7, 10, 0, 10, 11, 11, 10, 2, 5, 11, 4, 1, 5, 9, 7, 1, 8, 10, 7, 6,
+                 3, 9, 4, 3, 4, 2, 3, 2, 6, 3, 6, 8, 3, 8, 9, 9, 8, 1, 4, 9, 5, 2, 4, 11, 6, 2, 10, 8, 6, 7]
+
+    def add_midpoint(a, b):
+        for k in range(3):
+            vertices.append((vertices[3 * a + k] + vertices[3 * b + k]) / 2)
+        return len(vertices) // 3 - 1
+
+    prev = triangles
+    for _ in range(order):
+        triangles = []
+        for k in range(0, len(prev), 3):
+            v1, v2, v3 = prev[k], prev[k + 1], prev[k + 2]
+            a, b, c = add_midpoint(v1, v2), add_midpoint(v2, v3), add_midpoint(v3, v1)
+            triangles += [v1, a, c, v2, b, a, v3, c, b, a, b, c]
+        prev = triangles
+    v = np.array(vertices).reshape(-1, 3)
+    for i in range(len(v)):
+        m = 1 / math.sqrt(v[i, 0] ** 2 + v[i, 1] ** 2 + v[i, 2] ** 2)
+        v[i] = v[i] * m
+    return v[np.array(triangles)]
+
+
+def icosphere_scene(order, vw=800, vh=600):
+    """scenes/icosahedron.sdl with `order` subdivisions (the reference's README shows orders 0, 2 and 5 as
+    images/readme/11_22_2021_{1,2,3}.png): default camera, one default sun along <-0.8, -1, -0.4>, default (Normal)
+    skybox, the icosphere as a mesh of unshared triangles (flat normals from recalculate_normals, mesh.rs:208-254),
+    scale 2 at <0, 0, -6>."""
+    s = Scene()
+    s.set_camera(Camera(vw=vw, vh=vh))
+    s.add_light(sdl_sun((-0.8, -1., -0.4)))
+    soup = icosphere_soup(order)
+    m = Mesh(sdl_material())
+    m.set_geometry(soup, np.arange(len(soup), dtype=np.uint32).reshape(-1, 3))
+    sdl_mesh(m, position=(0., 0., -6.), scale=2.)
+    s.add(m)
+    return s

@@ -594,3 +594,26 @@ def test_batched_shards_of_a_camera_path_equal_the_frames_rendered_one_by_one():
         with pytest.raises(N.RtError) as e:
             ctx.render_shard_batch(0, n_shards, bad, gathered.data_ptr())
         assert e.value.code == N.RT_ERR_INVALID
+
+
+def test_device_frames_equal_the_reference_authors_own_renders(gpu_ctx):
+    """The device path against output the reference itself holds (no oracle in between): the three icosphere images
+    of its README (scenes/icosahedron.sdl, orders 0, 2, 5) byte for byte, and the 1920x1080 cube scene of
+    README.md:172-247 but for a dozen pixels on the cube whose position had to be fitted."""
+    from raytracer_amd.scene import read_png
+    for k, order in ((1, 0), (2, 2), (3, 5)):
+        golden = read_png(os.path.join(GOLDEN, f"readme_11_22_2021_{k}.png"))
+        gpu_ctx.upload(scenes.icosphere_scene(order))
+        rgb, _, st = gpu_ctx.render()
+        assert np.array_equal(rgb, golden), order
+    golden = read_png(os.path.join(GOLDEN, "readme_10_7_2021.png"))
+    tex = read_png(os.path.join(GOLDEN, "uwl.png"))
+    s = scenes.readme_10_7_scene(texture_pixels=tex, point_intensity=2. * (1.5 / 2.) ** 2)   # that build's METER: see test_oracle_kat.py
+    gpu_ctx.upload(s)
+    rgb, ids, st = gpu_ctx.render(ids=True)
+    d = np.abs(golden.astype(int) - rgb.astype(int)).max(axis=2)
+    assert (d == 0).mean() >= 0.9999 and (d > 1).sum() <= 16
+    assert (d[ids[..., 0] != 0] > 0).sum() <= 4
+    golden = read_png(os.path.join(GOLDEN, "readme_10_19_2021.png"))
+    gpu_ctx.upload(scenes.loop_scene(800, 600))
+    assert np.array_equal(gpu_ctx.render()[0], golden)

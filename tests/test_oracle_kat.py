@@ -309,6 +309,8 @@ def test_cubemap_bilinear_nan_quirk():
     c = sky(sb, (0.2, 0.3, -1.0))
     assert all(199 <= x <= 200 for x in c)
 
+N_NONE = 0xFFFFFFFF
+
 
 # ---------------------------------------------------------------- weak golden
 def test_weak_golden_ring_scene():
@@ -321,3 +323,52 @@ def test_weak_golden_ring_scene():
     assert (d <= 1).mean() >= 0.999
     assert (d == 0).mean() >= 0.999
     assert oc.would_panic == 0
+
+
+def test_golden_icospheres_of_the_readme():
+    """images/readme/11_22_2021_{1,2,3}.png: the reference author's renders of scenes/icosahedron.sdl with 0, 2 and 5
+    subdivisions (20, 320 and 20,480 triangles; a 2021-11-22 build).  They pin the mesh path to reference-held output:
+    the BVH built over the triangles and its walk (mesh.rs:326-345, acceleration.rs:296-405), Moeller-Trumbore
+    (mesh.rs:25-59), recalculate_normals and the interpolated normal (mesh.rs:208-254, 79-89), sun shading with the
+    shadow ray leaving a triangle by EPSILON (sun.rs:72-97), Normal skybox.  Reproduced on every byte."""
+    for k, order in ((1, 0), (2, 2), (3, 5)):
+        golden = read_png(os.path.join(GOLDEN, f"readme_11_22_2021_{k}.png"))
+        assert golden.shape == (600, 800, 3)
+        s = scenes.icosphere_scene(order)
+        rgb, ids, st, oc = oracle.render(s, 0)
+        assert np.array_equal(rgb, golden), order
+        assert oc.would_panic == 0
+        hit = ids[..., 0] == 0
+        assert 0.15 < hit.mean() < 0.3 and len(np.unique(ids[..., 1][hit])) >= (8, 100, 6000)[k - 1]   # (triangles facing the camera)
+
+
+# The 2021-10-07 build divided the distance to a point light by 1.5 where v2 divides by METER = 2
+# (lighting/mod.rs:13, point.rs:102): I / (d / 1.5)^2 = (I * 0.5625) / (d / 2)^2.  Found from the image itself: over
+# the checkered floor the light's contribution is 0.5625 (+- 0.005) of what v2 gives, at every distance.
+README_10_7_POINT_INTENSITY = 2. * (1.5 / 2.) ** 2
+
+
+def test_golden_readme_10_7_scene():
+    """images/readme/10_7_2021.png: the reference author's 1920x1080 render of README.md:172-247 (= scenes/uwl_cube.sdl).
+    Deterministic but for the cube's position, drawn from random(); fitted to 1e-5 by tools/fit_readme_10_7.py.  With
+    that position (and the point light's intensity rescaled for that build's METER, above) the oracle reproduces the
+    image on all but a dozen of its 2,073,600 pixels: cube with an image texture and per-face uv (aabb.rs:18-67),
+    checkered plane (plane.rs:49-79, material.rs:133-140), mirror sphere (scene.rs:182-196), point light with shadow
+    casts and falloff (point.rs:66-105), sun with shadows, Normal skybox seen directly and in the mirror."""
+    golden = read_png(os.path.join(GOLDEN, "readme_10_7_2021.png"))
+    assert golden.shape == (1080, 1920, 3)
+    tex = read_png(os.path.join(GOLDEN, "uwl.png"))
+    s = scenes.readme_10_7_scene(texture_pixels=tex, point_intensity=README_10_7_POINT_INTENSITY)
+    rgb, ids, st, oc = oracle.render(s, 0)
+    d = np.abs(golden.astype(int) - rgb.astype(int)).max(axis=2)
+    assert (d == 0).mean() >= 0.9999                        # measured: 14 pixels differ
+    assert (d > 1).sum() <= 16
+    # the few that differ sit on the cube (its fitted edges, texel boundaries), not on what the other objects pin
+    for obj, allowed in ((1, 2), (2, 0), (3, 0), (4, 2), (N_NONE, 0)):
+        assert (d[ids[..., 0] == obj] > 0).sum() <= allowed, obj
+    assert set(np.unique(ids[..., 0]).tolist()) == {0, 1, 2, 3, 4, N_NONE}
+    # with v2's own METER the same scene is another picture: the constant is what differs, not the formula
+    s2 = scenes.readme_10_7_scene(texture_pixels=tex)
+    px = np.random.default_rng(0).choice(1920 * 1080, 20000, replace=False).astype(np.uint32)
+    rgb2 = oracle.render(s2, 0, pixels=px, ids=False)[0]
+    assert (np.abs(rgb2.astype(int) - golden.reshape(-1, 3)[px].astype(int)).max(axis=1) > 1).mean() > 0.3
