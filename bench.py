@@ -76,13 +76,64 @@ def cpu_leg(scene, vw, vh, seconds, cores, frame_rgb):
     }
 
 
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _atlas():
+    # the reference's cubemap, assets/storforsen_4.jpg, is 8192 x 6144 (151 MB as RGB): a procedural atlas of that size,
+    # so that the sky lookups gather from as large an image (skybox.rs:64-86)
+    from raytracer_amd import scenes
+    return scenes.procedural_cubemap(2048)
+
+
+def _config2(vw, vh, args):
+    from raytracer_amd import scenes
+    return scenes.refraction_scene(vw, vh, cubemap=_atlas()), "scenes/refraction.sdl (3 spheres, 1 plane, sun, 8192x6144 cubemap)"
+
+
+def _config3(vw, vh, args):
+    import raytracer_amd as ra
+    s = ra.LoadedScene(os.path.join(GOLDEN, "fedora_192x108.rtscene")).set_resolution(vw, vh).set_cubemap(_atlas())
+    return s, "scenes/fedora.sdl (1038-triangle textured mesh over a mirror plane, sun, 8192x6144 cubemap)"
+
+
+def _config3b(vw, vh, args):
+    import raytracer_amd as ra
+    s = ra.LoadedScene(os.path.join(GOLDEN, "teapot_128x72.rtscene")).set_resolution(vw, vh)
+    return s, "scenes/bunny.sdl with assets/teapot.obj (6320 triangles, normals recalculated) for the missing bunny"
+
+
+def _config4(vw, vh, args):
+    from raytracer_amd import scenes
+    s = scenes.synthetic_terrain_scene(vw, vh, cells=args.cells, n_lights=args.lights)
+    return s, (f"synthetic height field ({args.cells}x{args.cells} cells) + 1 glass sphere + {args.lights} point lights with shadows")
+
+
+def _config5a(vw, vh, args):
+    from raytracer_amd import scenes
+    return scenes.huge_grid_scene(vw, vh, n=12, cubemap=scenes.procedural_cubemap(1024, seed=3)), "scenes/huge_grid.sdl (1728 jittered glass spheres, sun, 4096x3072 star atlas)"
+
+
+def _config5b(vw, vh, args):
+    from raytracer_amd import scenes
+    return scenes.terrain_scene(vw, vh), "scenes/terrain.sdl (72x72 grid = 10,082 triangles, reflectiveness 0.8, sun)"
+
+
+# name -> (builder, default resolution)
+CONFIGS = {"2": (_config2, (1920, 1080)), "3": (_config3, (3840, 2160)), "3b": (_config3b, (3840, 2160)),
+           "4": (_config4, (3840, 2160)), "5a": (_config5a, (7680, 4320)), "5b": (_config5b, (7680, 4320))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--config", default="4", choices=sorted(CONFIGS),
+                    help="BASELINE configuration: 2 refraction.sdl 1080p; 3 fedora.sdl 4K; 3b the teapot standing in for bunny.sdl 4K; "
+                         "4 (default, the headline) 1M-triangle terrain 4K; 5a huge_grid.sdl 8K; 5b terrain.sdl 8K")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--cells", type=int, default=708)
     ap.add_argument("--lights", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -117,9 +168,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    vw, vh = args.width, args.height
+    builder, (dw, dh) = CONFIGS[args.config]
+    vw, vh = args.width or dw, args.height or dh
     t0 = time.perf_counter()
-    scene = scenes.synthetic_terrain_scene(vw, vh, cells=args.cells, n_lights=args.lights)
+    scene, what = builder(vw, vh, args)
     t_build = time.perf_counter() - t0
     t_upload = [0.0]
 
@@ -136,12 +188,13 @@ def main():
     if args.batch is None:
         args.batch = 1 if world == 1 else min(world, 8)
     if args.frames_in_flight is None:
-        args.frames_in_flight = 4 if args.batch == 1 else 2
+        # (an 8K frame's wavefront levels take tens of GB per frame in flight)
+        args.frames_in_flight = 4 if args.batch == 1 and vw * vh <= 3840 * 2160 else 2
     depth, batch = max(1, args.frames_in_flight), max(1, args.batch)
     pipe = rd.FramePipeline(make_context, rank, world, device, depth=depth, batch=batch)
     t_upload = t_upload[0]
     info = ra.desc_info(scene.flatten())
-    camera_of = (lambda f: scene.camera) if batch > 1 else None     # the sequence: the same view, frame after frame
+    camera_of = None     # the sequence: the same view, frame after frame
 
     def sync():
         torch.cuda.synchronize(device)
@@ -260,7 +313,7 @@ def main():
         b_alg["GB/s_over_frame_time"] = b_alg["total"] / (ms_per_step * 1e-3) / 1e9
 
         roofline = None
-        if serial and serial["k_shadow_main_avg_launch_ms"] > 0:
+        if serial and serial["k_shadow_main_avg_launch_ms"] > 0 and args.config == "4":
             dur = serial["k_shadow_main_avg_launch_ms"] * 1e-3          # exclusive, measured in this run
             n_l = serial["k_shadow_main_launches_per_frame"]
             fr = {}
@@ -302,9 +355,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"synthetic {info['n_tris']}-triangle height field ({args.cells}x{args.cells} cells) + 1 glass sphere + "
-                            f"{args.lights} point lights with shadows, {vw}x{vh}, max_ray_depth 4 (BASELINE config 4)",
-                "resolution": [vw, vh], "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "lights": args.lights,
+                "workload": f"{what}, {info['n_tris']} triangles, {vw}x{vh}, max_ray_depth 4 (BASELINE config {args.config})",
+                "resolution": [vw, vh], "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "lights": info["n_lights"],
                 "parallelism": f"64x64-pixel supertiles interleaved over {world} GPU(s), gather to rank 0",
                 "sets_of_launches_in_flight": depth, "frames_per_set_of_launches": batch,
             },

@@ -272,7 +272,8 @@ int rt_detile(rt_ctx* ctx, const void* d_gathered, uint32_t n_shards,
 /* The sequence workload (sdl/src/main.rs:70-95 renders frame after frame) on a GPU that owns one shard of every
  * frame: renders shard `shard` of n_frames frames that differ in their camera only -- a camera path through the
  * uploaded scene -- as ONE set of launches, so that the launches of a small shard stay large enough to fill the
- * chip.  cameras[f].vw/vh must equal the uploaded scene's.  Frame f's compact shard (layout as rt_render_shard)
+ * chip.  cameras[f].vw/vh must equal the uploaded scene's; cameras == NULL: every frame through the uploaded scene's
+ * own camera (a still held for n_frames frames).  Frame f's compact shard (layout as rt_render_shard)
  * starts at slot f * frame_stride of d_rgb / d_ids; frame_stride >= rt_shard_pixels() (ranks pad to the largest
  * shard, shard 0's, so that gathered buffers line up: rt_detile_frames).  1 <= n_frames <= RT_BATCH_MAX. */
 #define RT_BATCH_MAX 64u

@@ -164,6 +164,7 @@ def host():
             "rth_scene_flatten": ([vp], vp), "rth_scene_save": ([vp, C.c_char_p], C.c_int),
             "rth_desc_load": ([C.c_char_p], vp), "rth_desc_get": ([vp], vp), "rth_desc_free": ([vp], None),
             "rth_desc_set_resolution": ([vp, i32, i32], None),
+            "rth_desc_set_cubemap": ([vp, u32, u32, vp], C.c_int),
             "rth_desc_info": ([vp, C.POINTER(C.c_uint32)], None),
             "rth_scene_render": ([vp, vp, C.c_int], C.c_int),
             "rth_scene_render_to": ([vp, C.c_char_p, C.c_int], C.c_int),

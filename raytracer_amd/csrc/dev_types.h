@@ -143,7 +143,7 @@ struct DLevel {
     double* hit_t; double* hit_t2;                // Hit::near, Hit::far
     float* hit_u; float* hit_v;                   // Hit::uv
     double* nrm[3];                               // Hit::normal
-    double* lit[3];                               // lit colour before the child mixes (scene.rs:122)
+    double* lit[3];                               // lit colour before the child mixes (scene.rs:122); shares nrm's memory
     double* w_t; double* w_r; double* emis;       // mix weights
     uint32_t* child0; uint32_t* child1;           // index in the next level (transmission, reflection)
     uint32_t* base_flags;                         // base colour rgb | flags << 24
@@ -163,6 +163,7 @@ struct DLevelCounts {
     unsigned long long hit_count;    // lit hits of this level (length of its k_shadow work list)
     unsigned long long long_trace;   // rays whose closest-hit walk gave up (entries of the level's long-ray list)
     unsigned long long long_shadow;  // shadow rays whose wave gave up
-    unsigned long long pad[12];
+    unsigned long long child_bound;  // upper bound of next_count, known before the level spawns (k_count_children)
+    unsigned long long pad[11];
 };
 struct DCounters { DShard shard[RT_SHARDS]; };

@@ -505,6 +505,28 @@ __global__ __launch_bounds__(RT_BLOCK) void k_spawn(const DScene* Sp, DLevel L, 
     if (COUNT) block_count3(vc.nodes, vc.tris, vc.units, &sh->nodes_visited, &sh->tris_tested, &sh->units_fetched);
 }
 
+// How many rays the level may spawn at most: one per hit on a transparent material, one per hit on a reflective one
+// (scene.rs:129,165,182; fewer are spawned when a refraction fails, scene.rs:140-153).  Lets the host give the next
+// level exactly the room it can need before k_spawn runs.
+__global__ __launch_bounds__(RT_BLOCK) void k_count_children(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, uint32_t depth, DLevelCounts* LC) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    n = level_size(n, n_dev);
+    if (blockIdx.x * RT_BLOCK >= n) return;
+    const DScene& S = *Sp;
+    uint32_t c = 0;
+    if (i < n && depth < S.max_depth) {
+        const uint32_t obj = L.hit_obj[i];
+        if (obj != RT_NONE && obj != RT_INACTIVE) {
+            const DMaterial& mat = S.materials[S.objects[obj].material];
+            if (!(mat.emissivity == 1.)) {
+                const bool t = mat.transparency > RT_EPSILON;
+                c = (t ? 1u : 0u) + ((mat.reflectiveness > RT_EPSILON && (t || mat.transparency < RT_EPSILON)) ? 1u : 0u);
+            }
+        }
+    }
+    block_count3(c, 0, 0, &LC->child_bound, nullptr, nullptr);
+}
+
 // The lit colour of every hit that k_spawn left pending (scene.rs:102-122), from the shadow casts' results.  A hit
 // without children is final here; the others keep the colour for k_resolve.
 __global__ __launch_bounds__(RT_BLOCK) void k_light(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, const uint8_t* occ, uint32_t stride) {

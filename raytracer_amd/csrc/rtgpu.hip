@@ -404,9 +404,9 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
 }
 
 size_t level_bytes(size_t cap) {
-    // 6+2+3+3+3 doubles, 2 floats, 6 u32 per slot; each array padded to 256 B
+    // 6+2+3+3 doubles, 2 floats, 6 u32 per slot; each array padded to 256 B
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return 17 * pad(cap * 8) + 2 * pad(cap * 4) + 6 * pad(cap * 4);
+    return 14 * pad(cap * 8) + 2 * pad(cap * 4) + 6 * pad(cap * 4);
 }
 
 int ensure_level(rt_ctx* c, size_t idx, size_t cap) {
@@ -428,7 +428,8 @@ int ensure_level(rt_ctx* c, size_t idx, size_t cap) {
     for (int k = 0; k < 3; k++) L.rd[k] = takeD();
     L.hit_t = takeD(); L.hit_t2 = takeD();
     for (int k = 0; k < 3; k++) L.nrm[k] = takeD();
-    for (int k = 0; k < 3; k++) L.lit[k] = takeD();
+    // the lit colour takes the normal's place: k_light, the normal's last reader, is the colour's writer (same thread, same slot)
+    for (int k = 0; k < 3; k++) L.lit[k] = L.nrm[k];
     L.w_t = takeD(); L.w_r = takeD(); L.emis = takeD();
     L.hit_u = takeF(); L.hit_v = takeF();
     L.hit_obj = takeU(); L.hit_prim = takeU(); L.child0 = takeU(); L.child1 = takeU(); L.base_flags = takeU(); L.result = takeU();
@@ -559,9 +560,9 @@ int ensure_level_counts(rt_ctx* c, size_t n) {
 //
 // How many rays a level holds is only known on the device, once the level above has spawned them.  A frame can be
 // rendered two ways:
-//   measured    (learned == nullptr) after each level the host reads the count back (one stream synchronisation per
-//               level), sizes the next level's buffers for the worst case (two children per ray) and its launches
-//               exactly;
+//   measured    (learned == nullptr) before a level spawns, a small kernel counts the hits that can spawn (an upper
+//               bound of the next level's size); the host reads that back (one stream synchronisation per level)
+//               and gives the next level exactly that room;
 //   speculative (learned = the level sizes of an earlier frame of this context and shard) every launch of the frame
 //               is queued at once: level d is given room for a quarter more rays than it held last time, its launches
 //               are sized for that room and read the real count from device memory.  If a level outgrows its room
@@ -618,13 +619,8 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
     for (uint32_t depth = 0; depth < room.size(); depth++) {
         const uint32_t n = room[depth];   // rays of this level (measured) or the room given to it (speculative)
         if (n == 0) break;
-        // the level's real size, for the kernels: on the device when it is not known here
-        const unsigned long long* n_dev = (learned && depth > 0) ? &c->d_lcounts[depth - 1].next_count : nullptr;
-        const bool can_spawn = depth < c->max_depth;
-        // measured: worst case, every ray spawns two children (scene.rs:134-172)
-        const size_t next_cap = learned ? (depth + 1 < room.size() ? room[depth + 1] : 0)
-                                        : (can_spawn ? std::min<size_t>((size_t)2 * n, 0x7FFFFFFEull) : 0);
-        if ((rc = ensure_level(c, depth + 1, std::max<size_t>(next_cap, 1))) != RT_OK) return rc;
+        // the level's real size, for the kernels: level 0's is n, the others' stands in device memory
+        const unsigned long long* n_dev = depth > 0 ? &c->d_lcounts[depth - 1].next_count : nullptr;
         if ((rc = ensure_level_work(c, depth, n)) != RT_OK) return rc;
         LevelWork& W = c->lw[depth];
         double* hs = static_cast<double*>(W.hs);
@@ -662,6 +658,19 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
             else hipLaunchKernelGGL(k_long_trace<false>, dim3(RT_LONG_BLOCKS), block, 0, s, c->dscene, c->levels[depth].lv, long_trace, hitlist, hs, n, dc, lc);
         }
         HIP_TRY(c, hipEventRecord(W.ev[LW_T1], s));
+        // Room for the next level.  Speculative: what it needed last time and a quarter.  Measured: a count of the
+        // hits that can spawn (one small kernel and one read-back per level), which bounds it from above.
+        size_t next_cap = 0;
+        if (learned) next_cap = depth + 1 < room.size() ? room[depth + 1] : 0;
+        else if (depth < c->max_depth) {
+            hipLaunchKernelGGL(k_count_children, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, n_dev, depth, lc);
+            HIP_TRY(c, hipMemcpyAsync(c->h_lcounts + depth, lc, sizeof(DLevelCounts), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            HIP_TRY(c, hipGetLastError());
+            next_cap = (size_t)std::min<unsigned long long>(c->h_lcounts[depth].child_bound, 0x7FFFFFFEull);
+            if (next_cap > 0) room.push_back((uint32_t)next_cap);
+        }
+        if ((rc = ensure_level(c, depth + 1, std::max<size_t>(next_cap, 1))) != RT_OK) return rc;
         {
             auto launch = [&](auto kern) {
                 hipLaunchKernelGGL(kern, grid, block, 0, s, c->dscene, c->levels[depth].lv, c->levels[depth + 1].lv, n, n_dev, depth,
@@ -704,14 +713,6 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
         hipLaunchKernelGGL(k_light, grid, block, 0, side, c->dscene, c->levels[depth].lv, n, n_dev, occ, n);
         HIP_TRY(c, hipEventRecord(W.ev[LW_L1], side));
         n_tr++; n_sh++;
-        if (!learned) {
-            HIP_TRY(c, hipMemcpyAsync(c->h_lcounts + depth, lc, sizeof(DLevelCounts), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
-            HIP_TRY(c, hipGetLastError());
-            const unsigned long long spawned = c->h_lcounts[depth].next_count;
-            if (spawned > next_cap) return fail(c, RT_ERR_DEVICE, "wavefront level overflow");
-            if (spawned > 0 && can_spawn) room.push_back((uint32_t)spawned);
-        }
     }
     size_t n_levels = 0;
     while (n_levels < room.size() && room[n_levels] > 0) n_levels++;
@@ -720,7 +721,7 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     for (int depth = (int)n_levels - 1; depth >= 0; depth--) {
         const uint32_t n = room[depth];
-        const unsigned long long* n_dev = (learned && depth > 0) ? &c->d_lcounts[depth - 1].next_count : nullptr;
+        const unsigned long long* n_dev = depth > 0 ? &c->d_lcounts[depth - 1].next_count : nullptr;
         hipLaunchKernelGGL(k_resolve, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, c->dscene, c->levels[depth].lv,
                            c->levels[depth + 1].lv, n, n_dev, depth == 0 ? 1 : 0, d_rgb, map);
     }
@@ -1176,24 +1177,26 @@ int rt_render_shard_batch(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t
     if (!d_rgb) return fail(c, RT_ERR_INVALID, "d_rgb is NULL");
     if (n_shards == 0 || shard >= n_shards) return fail(c, RT_ERR_INVALID, "bad shard arguments");
     if (n_frames == 0 || n_frames > RT_BATCH_MAX) return fail(c, RT_ERR_INVALID, "rt_render_shard_batch: n_frames must be 1.." + std::to_string(RT_BATCH_MAX));
-    if (!cameras) return fail(c, RT_ERR_INVALID, "rt_render_shard_batch: cameras is NULL");
     if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
     if (frame_stride < rt_shard_pixels(c->vw, c->vh, shard, n_shards) || frame_stride >= 0x7FFFFFFFll)
         return fail(c, RT_ERR_INVALID, "rt_render_shard_batch: frame_stride smaller than the shard (rt_shard_pixels)");
     auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(c, hipSetDevice(c->device));
-    c->h_cams.resize(n_frames);
-    for (uint32_t f = 0; f < n_frames; f++) {
-        if (cameras[f].vw != c->vw || cameras[f].vh != c->vh)
-            return fail(c, RT_ERR_INVALID, "rt_render_shard_batch: camera " + std::to_string(f) + " has another frame size than the uploaded scene");
-        c->h_cams[f] = make_camera(cameras[f]);
-    }
     int rc;
-    if ((rc = ensure_buf(c, &c->d_cams, &c->d_cams_cap, RT_BATCH_MAX * sizeof(DCamera))) != RT_OK) return rc;
-    // (pageable host memory: the copy has left h_cams when the call returns)
-    HIP_TRY(c, hipMemcpyAsync(c->d_cams, c->h_cams.data(), n_frames * sizeof(DCamera), hipMemcpyHostToDevice, c->stream));
+    if (cameras) {
+        c->h_cams.resize(n_frames);
+        for (uint32_t f = 0; f < n_frames; f++) {
+            if (cameras[f].vw != c->vw || cameras[f].vh != c->vh)
+                return fail(c, RT_ERR_INVALID, "rt_render_shard_batch: camera " + std::to_string(f) + " has another frame size than the uploaded scene");
+            c->h_cams[f] = make_camera(cameras[f]);
+        }
+        if ((rc = ensure_buf(c, &c->d_cams, &c->d_cams_cap, RT_BATCH_MAX * sizeof(DCamera))) != RT_OK) return rc;
+        // (pageable host memory: the copy has left h_cams when the call returns)
+        HIP_TRY(c, hipMemcpyAsync(c->d_cams, c->h_cams.data(), n_frames * sizeof(DCamera), hipMemcpyHostToDevice, c->stream));
+    }
     rt_stats st;
-    rc = render_frame(c, shard, n_shards, 0, static_cast<uint8_t*>(d_rgb), static_cast<uint32_t*>(d_ids), &st, n_frames, static_cast<const DCamera*>(c->d_cams), (uint32_t)frame_stride);
+    rc = render_frame(c, shard, n_shards, 0, static_cast<uint8_t*>(d_rgb), static_cast<uint32_t*>(d_ids), &st, n_frames,
+                      cameras ? static_cast<const DCamera*>(c->d_cams) : nullptr, (uint32_t)frame_stride);
     if (rc != RT_OK) return rc;
     st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (stats_out) *stats_out = st;

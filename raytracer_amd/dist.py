@@ -142,7 +142,7 @@ class ShardedRenderer:
         """this rank's shard into self.local: one frame through the scene's own camera, or one frame per camera"""
         if cameras is None:
             return self.ctx.render_shard(self.rank, self.world, self.local.data_ptr())
-        assert len(cameras) <= self.batch
+        assert (cameras if isinstance(cameras, int) else len(cameras)) <= self.batch
         return self.ctx.render_shard_batch(self.rank, self.world, cameras, self.local.data_ptr())
 
     def detile(self, gathered):
@@ -198,17 +198,16 @@ class FramePipeline:
     def run(self, n_frames, on_frame=None, camera_of=None):
         """Renders n_frames frames; on_frame(index, stats, frame_tensor_or_None) is called in frame order (stats: the
         RtStats of the set of launches the frame was part of, with .frames = how many frames that set covered).
-        camera_of(f) -> Camera of frame f; required when batch > 1, optional otherwise (None: the scene's camera).
+        camera_of(f) -> Camera of frame f; None: every frame through the scene's own camera.
         Returns the list of RtStats of this rank, one per set of launches."""
-        if self.batch > 1 and camera_of is None:
-            raise ValueError("a batched pipeline needs the frames' cameras (camera_of)")
         B = self.batch
         n_jobs = (n_frames + B - 1) // B
 
         def job(j):
             lo, hi = j * B, min((j + 1) * B, n_frames)
-            cams = None if camera_of is None else self.ctxs[j % self.depth].camera_array([camera_of(f) for f in range(lo, hi)])
-            return (j, cams)
+            if camera_of is not None:
+                return (j, self.ctxs[j % self.depth].camera_array([camera_of(f) for f in range(lo, hi)]))
+            return (j, None if B == 1 else hi - lo)
 
         stats = []
         for j in range(min(self.depth, n_jobs)):

@@ -202,6 +202,13 @@ void rth_desc_keep_meshes(const rt_scene_desc* d, int keep) {
 void rth_desc_set_resolution(LoadedDesc* l, int32_t vw, int32_t vh) {
     rt_scene_desc* d = const_cast<rt_scene_desc*>(desc_of(l)); d->camera.vw = vw; d->camera.vh = vh;
 }
+// Points a loaded scene's skybox at a caller-owned 4x3 cubemap atlas (kept alive by the caller while the scene is used)
+int rth_desc_set_cubemap(LoadedDesc* l, uint32_t w, uint32_t h, const uint8_t* rgb) {
+    if (!rgb || w < 4 || w / 4 != h / 3) { g_err = "cubemap: width/4 must equal height/3 (skybox.rs:49-51)"; return -1; }
+    rt_scene_desc* d = const_cast<rt_scene_desc*>(desc_of(l));
+    d->skybox.kind = RT_SKY_CUBEMAP; d->skybox.w = w; d->skybox.h = h; d->skybox.rgb = rgb;
+    return 0;
+}
 void rth_desc_info(const rt_scene_desc* d, uint32_t* out) {   // vw, vh, n_objects, n_lights, n_meshes, total tris, total nodes, skybox kind
     out[0] = (uint32_t)d->camera.vw; out[1] = (uint32_t)d->camera.vh; out[2] = d->n_objects; out[3] = d->n_lights; out[4] = d->n_meshes;
     uint32_t t = 0, n = 0;

@@ -81,13 +81,17 @@ class Context:
     def render_shard_batch(self, shard, n_shards, cameras, d_rgb_ptr, d_ids_ptr=None, frame_stride=None):
         """rt_render_shard_batch: this shard of len(cameras) frames that differ in their camera only, in one set of
         launches; frame f's compact shard starts at slot f * frame_stride (default: the largest shard's size, shard
-        0's, which is what a gather across ranks needs).  `cameras`: Camera objects or a ready rt_camera array
-        (camera_array)."""
-        arr = cameras if isinstance(cameras, C.Array) else self.camera_array(cameras)
+        0's, which is what a gather across ranks needs).  `cameras`: Camera objects, a ready rt_camera array
+        (camera_array), or a frame count (every frame through the scene's own camera)."""
+        if isinstance(cameras, int):            # that many frames through the uploaded scene's own camera
+            n, arr = cameras, None
+        else:
+            arr = cameras if isinstance(cameras, C.Array) else self.camera_array(cameras)
+            n = len(arr)
         if frame_stride is None:
             frame_stride = self.shard_pixels(0, n_shards)
         st = N.RtStats()
-        self._check(N.gpu().rt_render_shard_batch(self._c, shard, n_shards, len(arr), arr, int(frame_stride), C.c_void_p(d_rgb_ptr),
+        self._check(N.gpu().rt_render_shard_batch(self._c, shard, n_shards, n, arr, int(frame_stride), C.c_void_p(d_rgb_ptr),
                                                   C.c_void_p(d_ids_ptr) if d_ids_ptr else None, C.byref(st)))
         return st
 

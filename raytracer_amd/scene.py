@@ -354,6 +354,13 @@ class LoadedScene:
     def set_resolution(self, vw, vh):
         N.host().rth_desc_set_resolution(self._h, int(vw), int(vh)); return self
 
+    def set_cubemap(self, pixels):
+        """replaces the skybox by a 4x3 cubemap atlas ((3*cell, 4*cell, 3) uint8)"""
+        self._sky = np.ascontiguousarray(pixels, dtype=np.uint8)
+        if N.host().rth_desc_set_cubemap(self._h, self._sky.shape[1], self._sky.shape[0], self._sky.ctypes.data):
+            raise RuntimeError(N.host_error())
+        return self
+
     def flatten(self):
         return N.host().rth_desc_get(self._h)
 

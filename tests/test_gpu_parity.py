@@ -617,3 +617,61 @@ def test_device_frames_equal_the_reference_authors_own_renders(gpu_ctx):
     golden = read_png(os.path.join(GOLDEN, "readme_10_19_2021.png"))
     gpu_ctx.upload(scenes.loop_scene(800, 600))
     assert np.array_equal(gpu_ctx.render()[0], golden)
+
+
+_ATLAS = {}
+
+
+def _atlas(cell, seed=1):
+    if (cell, seed) not in _ATLAS:
+        _ATLAS[(cell, seed)] = scenes.procedural_cubemap(cell, seed=seed)
+    return _ATLAS[(cell, seed)]
+
+
+def _full_size_scene(name):
+    if name == "config2":     # scenes/refraction.sdl, 1920x1080, an atlas as large as assets/storforsen_4.jpg (8192x6144, 151 MB)
+        return scenes.refraction_scene(1920, 1080, cubemap=_atlas(2048)), 1920, 1080
+    if name == "config3":     # scenes/fedora.sdl, 3840x2160, the same atlas
+        s = ra.LoadedScene(os.path.join(GOLDEN, "fedora_192x108.rtscene")).set_resolution(3840, 2160).set_cubemap(_atlas(2048))
+        return s, 3840, 2160
+    if name == "config3b":    # bunny.sdl's stand-in, the teapot
+        return ra.LoadedScene(os.path.join(GOLDEN, "teapot_128x72.rtscene")).set_resolution(3840, 2160), 3840, 2160
+    if name == "config5a":    # scenes/huge_grid.sdl, 7680x4320: 1728 glass spheres through the object tree
+        return scenes.huge_grid_scene(7680, 4320, n=12, cubemap=_atlas(1024, 3)), 7680, 4320
+    if name == "config5b":    # scenes/terrain.sdl, 7680x4320
+        return scenes.terrain_scene(7680, 4320), 7680, 4320
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name,sample", [("config2", 20000), ("config3", 20000), ("config3b", 10000), ("config5a", 1500), ("config5b", 10000)])
+def test_full_size_configs_sampled_and_properties(name, sample):
+    """The other BASELINE configurations at their full sizes: the oracle on a random pixel sample (the whole 8K frame
+    of huge_grid would take the CPU minutes), and properties that hold at any size: a second frame is identical, the
+    frame queued without level-size read-backs equals the measured one, the union of 8 shards is the frame, ray
+    counts add up."""
+    import torch
+    s, vw, vh = _full_size_scene(name)
+    with ra.Context(0) as ctx:
+        ctx.upload(s)
+        rgb, ids, st = ctx.render(ids=True)
+        assert rgb.shape == (vh, vw, 3) and st.rays_primary == vw * vh and st.speculative == 0
+        px = np.random.default_rng(11).choice(vw * vh, sample, replace=False).astype(np.uint32)
+        o_rgb, o_ids, o_st, oc = oracle.render(s, 0, pixels=px)
+        assert oc.would_panic == 0
+        g_rgb, g_ids = rgb.reshape(-1, 3)[px], ids.reshape(-1, 2)[px]
+        assert np.array_equal(g_ids, o_ids)
+        assert_parity(g_rgb, g_ids, o_rgb, o_ids, exact_floor=0.9999)
+        rgb2, ids2, st2 = ctx.render(ids=True)
+        assert st2.speculative == 1 and st2.respeculated == 0
+        assert np.array_equal(rgb, rgb2) and np.array_equal(ids, ids2) and ray_counts(st) == ray_counts(st2)
+        del rgb2, ids2
+        slots = rd.max_shard_slots(vw, vh, 8)
+        gathered = torch.zeros(8 * slots * 3, dtype=torch.uint8, device="cuda")
+        rays = 0
+        for k in range(8):
+            rays += ctx.render_shard(k, 8, gathered.data_ptr() + k * slots * 3).rays
+        frame = torch.zeros(vw * vh * 3, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.detile(gathered.data_ptr(), 8, slots, 3, frame.data_ptr())
+        assert np.array_equal(frame.cpu().numpy().reshape(vh, vw, 3), rgb)
+        assert rays == st.rays
