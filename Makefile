@@ -7,15 +7,27 @@ CXX     ?= g++
 ARCH    ?= gfx950
 
 GPU_SRC  := raytracer_amd/csrc/rtgpu.hip
-GPU_HDR  := raytracer_amd/csrc/kernels.h raytracer_amd/csrc/dev_packet.h raytracer_amd/csrc/dev_rt.h raytracer_amd/csrc/dev_types.h include/rtgpu.h
+GPU_HDR  := raytracer_amd/csrc/kernels.h raytracer_amd/csrc/dev_packet.h raytracer_amd/csrc/dev_rt.h raytracer_amd/csrc/dev_types.h raytracer_amd/csrc/bvh_build.h include/rtgpu.h
+BVH_SRC  := raytracer_amd/csrc/bvh_build.hip
+BVH_HDR  := raytracer_amd/csrc/bvh_build.h raytracer_amd/csrc/dev_types.h
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off
 HOST_SRC := raytracer_amd/host/mesh.cpp raytracer_amd/host/scene.cpp raytracer_amd/host/png.cpp raytracer_amd/host/jpeg.cpp raytracer_amd/host/sdl.cpp raytracer_amd/host/capi.cpp
 HOST_HDR := raytracer_amd/host/scene.hpp raytracer_amd/host/sdl.hpp raytracer_amd/host/rmath.hpp include/rtgpu.h
 
 all: raytracer_amd/librtgpu.so raytracer_amd/librthost.so oracle/liboracle.so
 
 # -ffp-contract=off: the reference never fuses a multiply-add; neither may the device code
-raytracer_amd/librtgpu.so: $(GPU_SRC) $(GPU_HDR)
-	$(HIPCC) -O3 -std=c++17 -fPIC -shared --offload-arch=$(ARCH) -ffp-contract=off -o $@ $(GPU_SRC)
+# two translation units (the tree builder pulls in the rocPRIM sort and compiles slowly; no device code calls across them)
+build/obj/rtgpu.o: $(GPU_SRC) $(GPU_HDR)
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $(GPU_SRC)
+
+build/obj/bvh_build.o: $(BVH_SRC) $(BVH_HDR)
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $(BVH_SRC)
+
+raytracer_amd/librtgpu.so: build/obj/rtgpu.o build/obj/bvh_build.o
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ build/obj/rtgpu.o build/obj/bvh_build.o
 
 raytracer_amd/librthost.so: $(HOST_SRC) $(HOST_HDR) raytracer_amd/librtgpu.so
 	$(CXX) -O2 -std=c++17 -fPIC -shared -pthread -ffp-contract=off -o $@ $(HOST_SRC) -Lraytracer_amd -lrtgpu -lz -Wl,-rpath,'$$ORIGIN'

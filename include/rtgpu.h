@@ -101,10 +101,13 @@ typedef struct rt_bvh_node {
  * texture coordinates.  tri_uv may be NULL (no texcoords => uv (0,0)). */
 typedef struct rt_mesh {
     const double*      verts;      uint32_t n_verts;                       /* [n][3] */
-    /* Sequences (sdl/src/main.rs:70-95 rebuilds and renders the scene once per frame): nonzero = this mesh --
-     * geometry, normals, texture coordinates and tree -- is the one that stood at the same index in the previous
-     * successful rt_scene_upload of the context.  Its device copy is then kept and the arrays here are not read
-     * (the counts still are, and must match).  Zero: uploaded afresh. */
+    /* Sequences (sdl/src/main.rs:70-95 rebuilds and renders the scene once per frame):
+     *   0  uploaded afresh;
+     *   1  this mesh -- geometry, normals, texture coordinates and tree -- is the one that stood at the same index in
+     *      the previous successful rt_scene_upload of the context: its device copy is kept and the arrays here are not
+     *      read (the counts still are, and must match);
+     *   2  same connectivity (tri_pos, tri_nrm, tri_uv, texcoords) and same tree as that mesh, but `verts` and `normals`
+     *      (same counts) are new: the kept tree's boxes and triangle records are recomputed on the device from them. */
     uint32_t           unchanged;
     const double*      normals;    uint32_t n_normals;    uint32_t _p1;   /* [n][3] */
     const float*       texcoords;  uint32_t n_texcoords;  uint32_t _p2;   /* [n][2] */
@@ -112,6 +115,11 @@ typedef struct rt_mesh {
     const uint32_t*    tri_nrm;                                            /* [n_tris][3] */
     const uint32_t*    tri_uv;                                             /* [n_tris][3] or NULL */
     uint32_t           n_tris;     uint32_t _p3;
+    /* The tree of Mesh::generate_sbvh (mesh.rs:257-272), built by the caller.  nodes == NULL with n_nodes == 0: no tree
+     * is handed over and the library builds one on the device (a linear BVH over the triangles' centroids; milliseconds
+     * for a million triangles, where the host's binned-SAH build takes a third of a second).  Frames do not depend
+     * on which tree is used, except between two triangles hit at exactly the same distance, where the earlier one
+     * in the tree's leaf order wins (mesh.rs:365-376: the earlier candidate of the reference's own tree). */
     const rt_bvh_node* nodes;      uint32_t n_nodes;      uint32_t _p4;
     const uint32_t*    prim_indices; uint32_t n_prims;    uint32_t _p5;
 } rt_mesh;

@@ -150,11 +150,14 @@ def host():
             "rth_mesh_shift": ([vp, dp], None), "rth_mesh_rotate_xyz": ([vp, dp], None), "rth_mesh_rotate_zyx": ([vp, dp], None),
             "rth_mesh_recalculate_normals": ([vp], None), "rth_mesh_generate_sbvh": ([vp], C.c_int),
             "rth_mesh_set_bvh": ([vp, vp, u32, vp, u32, u32], C.c_int),
+            "rth_mesh_use_device_bvh": ([vp, C.c_int], None),
+            "rth_mesh_set_verts": ([vp, u32, vp], C.c_int),
             "rth_desc_keep_meshes": ([vp, C.c_int], None),
             "rth_mesh_n_tris": ([vp], u32), "rth_mesh_n_verts": ([vp], u32), "rth_mesh_n_normals": ([vp], u32),
             "rth_mesh_n_nodes": ([vp], u32), "rth_mesh_bvh_depth": ([vp], u32),
             "rth_mesh_verts": ([vp], vp), "rth_mesh_normals": ([vp], vp), "rth_mesh_tri_normals": ([vp], vp), "rth_mesh_tris": ([vp], vp),
             "rth_add_mesh": ([vp, vp, C.POINTER(RthMaterial)], C.c_int),
+            "rth_scene_object_mesh": ([vp, u32], vp),
             "rth_add_sun": ([vp, u8p, dbl, i32, dbl, dp, C.c_int, dbl], C.c_int),
             "rth_add_point": ([vp, u8p, dbl, i32, dbl, dp, dbl], C.c_int),
             "rth_add_area": ([vp, u8p, dbl, i32, dbl, u32, dp, dbl, dp, u32, dbl], C.c_int),

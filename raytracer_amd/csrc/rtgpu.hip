@@ -24,6 +24,7 @@
 
 #include "../../include/rtgpu.h"
 #include "kernels.h"
+#include "bvh_build.h"
 
 namespace {
 
@@ -85,7 +86,11 @@ struct rt_ctx {
     std::vector<void*> scene_allocs;
     std::vector<void*>* alloc_sink = &scene_allocs;   // where upload() records what it allocates
     // the meshes of the last upload, each with the device memory it owns: a mesh flagged `unchanged` keeps its copy
-    struct MeshCopy { DMesh dm; std::vector<void*> allocs; size_t bytes = 0; uint32_t n_verts = 0, n_tris = 0, n_nodes = 0, n_prims = 0; };
+    struct MeshCopy {
+        DMesh dm; std::vector<void*> allocs; size_t bytes = 0; uint32_t n_verts = 0, n_tris = 0, n_nodes = 0, n_prims = 0;
+        uint32_t n_normals = 0;
+        const uint32_t* d_tri_pos = nullptr;   // the triangles' vertex indices, kept for refits (rt_mesh::unchanged == 2)
+    };
     std::vector<MeshCopy> mesh_copies;
     DScene hscene;                 // host copy of the device scene header
     DScene* dscene = nullptr;
@@ -222,7 +227,105 @@ void parallel_for(size_t n, F fn) {
     for (auto& t : th) t.join();
 }
 
-int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
+// f32 root box and coordinate bound of a mesh from its f64 bounds: rounded outward from the slab bounds the reference's
+// test uses, centroid -+ size with centroid = (min + max) * 0.5 and size = max - centroid (acceleration.rs:76,135)
+void set_root_box(DMesh& out, const double mn[3], const double mx[3]) {
+    for (int k = 0; k < 3; k++) {
+        const double cen = (mn[k] + mx[k]) * 0.5;
+        const double half = mx[k] - cen;
+        const double lo = std::fmin(mn[k], cen - half), hi = std::fmax(mx[k], cen + half);
+        float flo = (float)lo, fhi = (float)hi;
+        if ((double)flo > lo) flo = std::nextafterf(flo, -INFINITY);
+        if ((double)fhi < hi) fhi = std::nextafterf(fhi, INFINITY);
+        out.root_min[k] = flo; out.root_max[k] = fhi;
+    }
+    // every child box lies inside the root's (boxes are unions of their descendants'), up to the outward rounding
+    out.coord_max = 0.f;
+    for (int k = 0; k < 3; k++) out.coord_max = std::fmax(out.coord_max, std::fmax(std::fabs(out.root_min[k]), std::fabs(out.root_max[k])));
+    out.coord_max = out.coord_max * 1.000001f + 1e-30f;
+}
+
+int check_mesh_indices(rt_ctx* c, const rt_mesh& m) {
+    std::atomic<int> bad{0};   // 1 vertex, 2 normal, 3 texcoord
+    parallel_for((size_t)3 * m.n_tris, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            if (m.tri_pos[i] >= m.n_verts) { bad = 1; return; }
+            if (m.tri_nrm[i] >= m.n_normals) { bad = 2; return; }
+            if (m.tri_uv && m.n_texcoords && m.tri_uv[i] >= m.n_texcoords) { bad = 3; return; }
+        }
+    });
+    if (bad == 1) return fail(c, RT_ERR_INVALID, "mesh: vertex index out of range");
+    if (bad == 2) return fail(c, RT_ERR_INVALID, "mesh: normal index out of range");
+    if (bad == 3) return fail(c, RT_ERR_INVALID, "mesh: texcoord index out of range");
+    return RT_OK;
+}
+
+// the per-triangle attribute arrays every mesh carries, whoever built its tree
+int upload_mesh_attributes(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc) {
+    DMesh& out = mc.dm;
+    int rc;
+    out.n_tris = m.n_tris; out.n_texcoords = m.tri_uv ? m.n_texcoords : 0;
+    if ((rc = upload(c, m.normals, (size_t)m.n_normals * 3, &out.normals)) != RT_OK) return rc;
+    if ((rc = upload(c, m.texcoords, (size_t)m.n_texcoords * 2, &out.texcoords)) != RT_OK) return rc;
+    if ((rc = upload(c, m.tri_nrm, (size_t)m.n_tris * 3, &out.tri_nrm)) != RT_OK) return rc;
+    if (m.tri_uv && m.n_texcoords) { if ((rc = upload(c, m.tri_uv, (size_t)m.n_tris * 3, &out.tri_uv)) != RT_OK) return rc; }
+    if (!mc.d_tri_pos && (rc = upload(c, m.tri_pos, (size_t)m.n_tris * 3, &mc.d_tri_pos)) != RT_OK) return rc;
+    mc.n_normals = m.n_normals;
+    return RT_OK;
+}
+
+// rt_mesh::nodes == NULL: the tree is built here, on the device (bvh_build.h)
+int build_mesh_on_device(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc) {
+    DMesh& out = mc.dm;
+    std::memset(&out, 0, sizeof(out));
+    if (m.n_tris == 0 || !m.tri_pos || !m.tri_nrm || !m.verts) return fail(c, RT_ERR_INVALID, "mesh without triangles");
+    if (m.n_tris > RT_PACKET_MAX_PRIMS) return fail(c, RT_ERR_UNSUPPORTED, "mesh with more than " + std::to_string(RT_PACKET_MAX_PRIMS) + " triangles");
+    if (m.n_normals != 0 && !m.normals) return fail(c, RT_ERR_INVALID, "mesh: normals is NULL but n_normals is not 0");
+    if (m.n_texcoords != 0 && !m.texcoords) return fail(c, RT_ERR_INVALID, "mesh: texcoords is NULL but n_texcoords is not 0");
+    int rc;
+    if ((rc = check_mesh_indices(c, m)) != RT_OK) return rc;
+    if ((rc = upload(c, m.tri_pos, (size_t)m.n_tris * 3, &mc.d_tri_pos)) != RT_OK) return rc;
+    double* d_verts = nullptr;
+    if (hipMalloc((void**)&d_verts, (size_t)m.n_verts * 24) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipMalloc failed during scene upload");
+    hipError_t e = hipMemcpyAsync(d_verts, m.verts, (size_t)m.n_verts * 24, hipMemcpyHostToDevice, c->stream);
+    BvhBuildResult br;
+    if (e == hipSuccess) e = bvh_build_device(c->stream, d_verts, mc.d_tri_pos, m.n_tris, &br);
+    (void)hipFree(d_verts);
+    if (e != hipSuccess) return fail(c, RT_ERR_DEVICE, std::string("device BVH build: ") + hipGetErrorString(e));
+    if (br.nodes) { c->alloc_sink->push_back(br.nodes); c->scene_bytes += (size_t)br.n_inner * sizeof(DNode); }
+    c->alloc_sink->push_back(br.tris); c->scene_bytes += (size_t)m.n_tris * sizeof(DTri);
+    if (std::getenv("RTGPU_DEBUG_BVH")) std::fprintf(stderr, "device-built tree: wide nodes %u, stack %u, sort %.2f ms, total %.2f ms\n", br.n_inner, br.stack_need, br.ms_sort, br.ms_total);
+    if (br.stack_need > RT_PSTACK)
+        return fail(c, RT_ERR_UNSUPPORTED, "device-built BVH needs " + std::to_string(br.stack_need) + " stack entries (limit " + std::to_string(RT_PSTACK) +
+                                               "): build this mesh's tree on the host");
+    out.nodes = br.nodes; out.tris = br.tris; out.n_inner = br.n_inner; out.root_ref = br.root_ref;
+    set_root_box(out, br.root_box, br.root_box + 3);
+    return upload_mesh_attributes(c, m, mc);
+}
+
+// rt_mesh::unchanged == 2: same connectivity and tree as the kept copy, new vertex positions (and normals): triangle
+// records and boxes are recomputed on the device
+int refit_mesh(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc) {
+    if (!m.verts) return fail(c, RT_ERR_INVALID, "mesh to refit without vertices");
+    if (m.n_normals != mc.n_normals || (m.n_normals && !m.normals)) return fail(c, RT_ERR_INVALID, "mesh to refit: normals differ in number from the kept copy's");
+    double* d_verts = nullptr;
+    if (hipMalloc((void**)&d_verts, (size_t)m.n_verts * 24) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipMalloc failed during scene upload");
+    hipError_t e = hipMemcpyAsync(d_verts, m.verts, (size_t)m.n_verts * 24, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && m.n_normals)
+        e = hipMemcpyAsync(const_cast<double*>(mc.dm.normals), m.normals, (size_t)m.n_normals * 24, hipMemcpyHostToDevice, c->stream);
+    double root_box[6];
+    if (e == hipSuccess)
+        e = bvh_refit_device(c->stream, d_verts, mc.d_tri_pos, mc.n_tris, const_cast<DNode*>(mc.dm.nodes), mc.dm.n_inner, mc.dm.root_ref,
+                             const_cast<DTri*>(mc.dm.tris), root_box);
+    (void)hipFree(d_verts);
+    if (e != hipSuccess) return fail(c, RT_ERR_DEVICE, std::string("device BVH refit: ") + hipGetErrorString(e));
+    set_root_box(mc.dm, root_box, root_box + 3);
+    return RT_OK;
+}
+
+int upload_mesh(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc) {
+    if (!m.nodes && m.n_nodes == 0) return build_mesh_on_device(c, m, mc);
+    DMesh& out = mc.dm;
     std::memset(&out, 0, sizeof(out));
     const bool dbg = std::getenv("RTGPU_DEBUG_BVH") != nullptr;
     auto tm0 = std::chrono::steady_clock::now();
@@ -239,17 +342,8 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
     if (m.n_normals != 0 && !m.normals) return fail(c, RT_ERR_INVALID, "mesh: normals is NULL but n_normals is not 0");
     if (m.n_texcoords != 0 && !m.texcoords) return fail(c, RT_ERR_INVALID, "mesh: texcoords is NULL but n_texcoords is not 0");
     {
-        std::atomic<int> bad{0};   // 1 vertex, 2 normal, 3 texcoord
-        parallel_for((size_t)3 * m.n_tris, [&](size_t a, size_t b) {
-            for (size_t i = a; i < b; i++) {
-                if (m.tri_pos[i] >= m.n_verts) { bad = 1; return; }
-                if (m.tri_nrm[i] >= m.n_normals) { bad = 2; return; }
-                if (m.tri_uv && m.n_texcoords && m.tri_uv[i] >= m.n_texcoords) { bad = 3; return; }
-            }
-        });
-        if (bad == 1) return fail(c, RT_ERR_INVALID, "mesh: vertex index out of range");
-        if (bad == 2) return fail(c, RT_ERR_INVALID, "mesh: normal index out of range");
-        if (bad == 3) return fail(c, RT_ERR_INVALID, "mesh: texcoord index out of range");
+        const int rc_ = check_mesh_indices(c, m);
+        if (rc_ != RT_OK) return rc_;
     }
     // walk the tree iteratively: validate links, number inner nodes, measure depth
     const uint32_t NN = m.n_nodes;
@@ -312,6 +406,8 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
         struct Work { uint32_t ri, di, held; };
         std::vector<Work> work;
         nodes.emplace_back();
+        std::memset(&nodes.back(), 0, sizeof(DNode));
+        nodes.back().pad[0] = RT_NONE;
         work.push_back({0u, 0u, 0u});
         while (!work.empty()) {
             auto [ri, di, held] = work.back(); work.pop_back();
@@ -329,16 +425,27 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
             }
             // topology now (sequential: the numbering depends on it); the boxes are filled in afterwards, in parallel.
             // Until then pad[k] remembers which reference node slot k shows.
-            DNode dn;
-            std::memset(&dn, 0, sizeof(dn));
+            // (minx[k] holds, until the boxes are filled in, the number of the reference node slot k shows)
+            DNode dn = nodes[di];              // pad[0], pad[1] (parent record, slot in it) were set when the parent was emitted
             uint32_t child_dev[4] = {0, 0, 0, 0};
+            uint32_t n_inner_kids = 0;
             for (int k = 0; k < 4; k++) {
-                if (k >= nk) { dn.ref[k] = RT_NO_CHILD; dn.pad[k] = RT_NONE; continue; }
-                dn.pad[k] = kids[k];
-                const rt_bvh_node& kn = m.nodes[kids[k]];
-                if (kn.count != 0) dn.ref[k] = RT_LEAF_BIT | kn.right_or_first;
-                else { child_dev[k] = (uint32_t)nodes.size(); nodes.emplace_back(); dn.ref[k] = child_dev[k]; }
+                uint32_t shown = RT_NONE;
+                if (k >= nk) dn.ref[k] = RT_NO_CHILD;
+                else {
+                    shown = kids[k];
+                    const rt_bvh_node& kn = m.nodes[kids[k]];
+                    if (kn.count != 0) dn.ref[k] = RT_LEAF_BIT | kn.right_or_first;
+                    else {
+                        child_dev[k] = (uint32_t)nodes.size(); nodes.emplace_back(); dn.ref[k] = child_dev[k];
+                        std::memset(&nodes.back(), 0, sizeof(DNode));
+                        nodes.back().pad[0] = di; nodes.back().pad[1] = (uint32_t)k;
+                        n_inner_kids++;
+                    }
+                }
+                std::memcpy(&dn.minx[k], &shown, 4);
             }
+            dn.pad[2] = n_inner_kids; dn.pad[3] = (uint32_t)nk;   // (the refit's arrival count; children in use)
             nodes[di] = dn;
             // the packet walks stack every child that was entered and take the top one
             pstack_need = std::max(pstack_need, held + (uint32_t)nk);
@@ -351,17 +458,18 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
         for (size_t i = a; i < b; i++) {
             DNode& dn = nodes[i];
             for (int k = 0; k < 4; k++) {
-                if (dn.pad[k] == RT_NONE) {
+                uint32_t shown;
+                std::memcpy(&shown, &dn.minx[k], 4);
+                if (shown == RT_NONE) {
                     // empty slot: a box no ray enters
                     dn.minx[k] = dn.miny[k] = dn.minz[k] = INFINITY;
                     dn.maxx[k] = dn.maxy[k] = dn.maxz[k] = -INFINITY;
                 } else {
                     float bmin[3], bmax[3];
-                    box_of(dn.pad[k], bmin, bmax);
+                    box_of(shown, bmin, bmax);
                     dn.minx[k] = bmin[0]; dn.miny[k] = bmin[1]; dn.minz[k] = bmin[2];
                     dn.maxx[k] = bmax[0]; dn.maxy[k] = bmax[1]; dn.maxz[k] = bmax[2];
                 }
-                dn.pad[k] = 0;
             }
         }
     });
@@ -385,20 +493,13 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, DMesh& out) {
     });
     if (!last[m.n_prims - 1]) return fail(c, RT_ERR_INVALID, "mesh BVH: leaf list does not end on a leaf boundary");
     lap("triangles");
-    box_of(0, out.root_min, out.root_max);
-    // every child box lies inside the root's (boxes are unions of their descendants'), up to the outward rounding
-    out.coord_max = 0.f;
-    for (int k = 0; k < 3; k++) out.coord_max = std::fmax(out.coord_max, std::fmax(std::fabs(out.root_min[k]), std::fabs(out.root_max[k])));
-    out.coord_max = out.coord_max * 1.000001f + 1e-30f;
+    set_root_box(out, m.nodes[0].min, m.nodes[0].max);
     out.root_ref = m.nodes[0].count == 0 ? 0u : (RT_LEAF_BIT | m.nodes[0].right_or_first);
-    out.n_inner = n_inner; out.n_tris = m.n_tris; out.n_texcoords = m.tri_uv ? m.n_texcoords : 0;
+    out.n_inner = n_inner;
     int rc;
     if ((rc = upload(c, nodes.data(), nodes.size(), &out.nodes)) != RT_OK) return rc;
     if ((rc = upload(c, tris.get(), (size_t)m.n_prims, &out.tris)) != RT_OK) return rc;
-    if ((rc = upload(c, m.normals, (size_t)m.n_normals * 3, &out.normals)) != RT_OK) return rc;
-    if ((rc = upload(c, m.texcoords, (size_t)m.n_texcoords * 2, &out.texcoords)) != RT_OK) return rc;
-    if ((rc = upload(c, m.tri_nrm, (size_t)m.n_tris * 3, &out.tri_nrm)) != RT_OK) return rc;
-    if (m.tri_uv && m.n_texcoords) { if ((rc = upload(c, m.tri_uv, (size_t)m.n_tris * 3, &out.tri_uv)) != RT_OK) return rc; }
+    if ((rc = upload_mesh_attributes(c, m, mc)) != RT_OK) return rc;
     lap("copies");
     return RT_OK;
 }
@@ -978,16 +1079,20 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
         for (uint32_t i = 0; i < d->n_meshes && rc == RT_OK; i++) {
             const rt_mesh& m = d->meshes[i];
             rt_ctx::MeshCopy& mc = c->mesh_copies[i];
-            if (m.unchanged) {
+            if (m.unchanged > 2) rc = fail(c, RT_ERR_INVALID, "mesh " + std::to_string(i) + ": unchanged must be 0, 1 or 2");
+            else if (m.unchanged) {
                 if (i >= old.size() || old[i].allocs.empty())
                     rc = fail(c, RT_ERR_INVALID, "mesh " + std::to_string(i) + " is flagged unchanged, but the last upload holds no mesh at that index");
-                else if (old[i].n_verts != m.n_verts || old[i].n_tris != m.n_tris || old[i].n_nodes != m.n_nodes || old[i].n_prims != m.n_prims)
+                else if (old[i].n_verts != m.n_verts || old[i].n_tris != m.n_tris || (m.unchanged == 1 && (old[i].n_nodes != m.n_nodes || old[i].n_prims != m.n_prims)))
                     rc = fail(c, RT_ERR_INVALID, "mesh " + std::to_string(i) + " is flagged unchanged, but its counts differ from the last upload's");
-                else { mc = std::move(old[i]); old[i].allocs.clear(); c->scene_bytes += mc.bytes; }
+                else {
+                    mc = std::move(old[i]); old[i].allocs.clear(); c->scene_bytes += mc.bytes;
+                    if (m.unchanged == 2) rc = refit_mesh(c, m, mc);
+                }
             } else {
                 const size_t before = c->scene_bytes;
                 c->alloc_sink = &mc.allocs;
-                rc = upload_mesh(c, m, mc.dm);
+                rc = upload_mesh(c, m, mc);
                 c->alloc_sink = &c->scene_allocs;
                 mc.bytes = c->scene_bytes - before;
                 mc.n_verts = m.n_verts; mc.n_tris = m.n_tris; mc.n_nodes = m.n_nodes; mc.n_prims = m.n_prims;

@@ -115,6 +115,13 @@ void rth_mesh_rotate_xyz(std::shared_ptr<Mesh>* m, const double* r) { (*m)->rota
 void rth_mesh_rotate_zyx(std::shared_ptr<Mesh>* m, const double* r) { (*m)->rotate_zyx(V(r)); }
 void rth_mesh_recalculate_normals(std::shared_ptr<Mesh>* m) { (*m)->recalculate_normals(); }
 int rth_mesh_generate_sbvh(std::shared_ptr<Mesh>* m) { std::string e; return (*m)->generate_sbvh(e) ? 0 : fail(e); }
+int rth_mesh_set_verts(std::shared_ptr<Mesh>* m, uint32_t n, const double* verts) {
+    if (!verts || n != (*m)->verts.size()) return fail("set_verts: the number of vertices must not change");
+    for (uint32_t i = 0; i < n; i++) (*m)->verts[i] = Vector3{verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]};
+    return 0;
+}
+// The tree is left to the render library: the flattened mesh carries no nodes and rt_scene_upload builds them on the device.
+void rth_mesh_use_device_bvh(std::shared_ptr<Mesh>* m, int on) { (*m)->device_bvh = on != 0; }
 // Mesh::sbvh is a public field of the reference (mesh.rs:118): a caller may install a tree of their own.  The nodes
 // are taken as given (rt_bvh_node layout: a node's first child is the next record); upload validates them.
 int rth_mesh_set_bvh(std::shared_ptr<Mesh>* m, const rt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* prim_indices, uint32_t n_prims, uint32_t depth) {
@@ -141,6 +148,13 @@ int rth_add_mesh(Scene* s, std::shared_ptr<Mesh>* m, const rth_material* mat) {
     copy->material = M(mat);
     SceneObject o; o.kind = SceneObject::KMesh; o.mesh = copy;
     s->objects.push_back(std::move(o)); return (int)s->objects.size() - 1;
+}
+
+// A handle on the mesh object `index` of the scene holds (rth_add_mesh copied the caller's): changes through it
+// (rth_mesh_set_verts, rth_mesh_recalculate_normals ...) show in the scene's next flatten.  NULL if it is no mesh.
+std::shared_ptr<Mesh>* rth_scene_object_mesh(Scene* s, uint32_t index) {
+    if (index >= s->objects.size() || s->objects[index].kind != SceneObject::KMesh) { g_err = "object is not a mesh"; return nullptr; }
+    return new std::shared_ptr<Mesh>(s->objects[index].mesh);
 }
 
 // ---- lights
@@ -195,9 +209,10 @@ LoadedDesc* rth_desc_load(const char* path) { std::string e; LoadedDesc* l = loa
 const rt_scene_desc* rth_desc_get(LoadedDesc* l) { return desc_of(l); }
 void rth_desc_free(LoadedDesc* l) { free_desc(l); }
 // Sequences: marks every mesh of a flattened scene as unchanged since the context's last upload (rt_mesh::unchanged).
+// (keep: 0 uploaded afresh, 1 unchanged, 2 same connectivity and tree with new vertex positions and normals: refitted)
 void rth_desc_keep_meshes(const rt_scene_desc* d, int keep) {
     rt_mesh* m = const_cast<rt_mesh*>(d->meshes);
-    for (uint32_t i = 0; i < d->n_meshes; i++) m[i].unchanged = keep ? 1u : 0u;
+    for (uint32_t i = 0; i < d->n_meshes; i++) m[i].unchanged = (uint32_t)(keep < 0 ? 0 : keep > 2 ? 2 : keep);
 }
 void rth_desc_set_resolution(LoadedDesc* l, int32_t vw, int32_t vh) {
     rt_scene_desc* d = const_cast<rt_scene_desc*>(desc_of(l)); d->camera.vw = vw; d->camera.vh = vh;

@@ -83,7 +83,7 @@ const rt_scene_desc* Scene::flatten(std::string& err) {
             }
             case SceneObject::KMesh: {
                 const Mesh* mp = o.mesh.get();
-                if (!mp || !mp->sbvh) { err = "mesh without an acceleration structure (mesh.rs:350 asserts sbvh.is_some())"; return nullptr; }
+                if (!mp || (!mp->sbvh && !mp->device_bvh)) { err = "mesh without an acceleration structure (mesh.rs:350 asserts sbvh.is_some())"; return nullptr; }
                 auto it = mesh_ids.find(mp);
                 if (it == mesh_ids.end()) {
                     if (mp->tri_normals.size() != mp->tris.size()) { err = "mesh: tri_normals and tris differ in length"; return nullptr; }
@@ -96,8 +96,10 @@ const rt_scene_desc* Scene::flatten(std::string& err) {
                     rm2.tri_nrm = reinterpret_cast<const uint32_t*>(mp->tri_normals.data());
                     rm2.tri_uv = mp->tri_texcoords.empty() ? nullptr : reinterpret_cast<const uint32_t*>(mp->tri_texcoords.data());
                     rm2.n_tris = (uint32_t)mp->tris.size();
-                    rm2.nodes = mp->sbvh->nodes.data(); rm2.n_nodes = (uint32_t)mp->sbvh->nodes.size();
-                    rm2.prim_indices = mp->sbvh->prim_indices.data(); rm2.n_prims = (uint32_t)mp->sbvh->prim_indices.size();
+                    if (!mp->device_bvh) {
+                        rm2.nodes = mp->sbvh->nodes.data(); rm2.n_nodes = (uint32_t)mp->sbvh->nodes.size();
+                        rm2.prim_indices = mp->sbvh->prim_indices.data(); rm2.n_prims = (uint32_t)mp->sbvh->prim_indices.size();
+                    }
                     it = mesh_ids.emplace(mp, (uint32_t)f.meshes.size()).first;
                     f.meshes.push_back(rm2);
                 }

@@ -63,6 +63,7 @@ struct Mesh {
     std::vector<std::array<uint32_t, 3>> tri_texcoords;
     Material material;
     std::shared_ptr<FlatBvh> sbvh;
+    bool device_bvh = false;               // leave the tree to the render library (rt_mesh::nodes == NULL: built on the device)
 
     static bool from_obj(const std::string& file_name, Material material, Mesh& out, std::string& err);   // mesh.rs:135-205
     void recalculate_normals();            // mesh.rs:208-254

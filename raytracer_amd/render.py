@@ -41,10 +41,12 @@ class Context:
         """scene: anything with .flatten() -> rt_scene_desc address (Scene, LoadedScene).
         keep_meshes: the caller's promise that every mesh (geometry, normals, texture coordinates, tree) is the one
         of this context's previous upload, as in a sequence where only the camera, lights, materials or the other
-        objects move: their device copies are kept (rt_mesh::unchanged)."""
+        objects move: their device copies are kept (rt_mesh::unchanged).  keep_meshes="refit": connectivity and tree are
+        the previous upload's, vertex positions and normals are new: boxes and triangle records are recomputed on the
+        device (rt_mesh::unchanged = 2)."""
         from .scene import desc_info
         p = scene.flatten()
-        N.host().rth_desc_keep_meshes(p, 1 if keep_meshes else 0)
+        N.host().rth_desc_keep_meshes(p, 2 if keep_meshes == "refit" else 1 if keep_meshes else 0)
         self._check(N.gpu().rt_scene_upload(self._c, p))
         info = desc_info(p)
         self.vw, self.vh = info["vw"], info["vh"]

@@ -155,8 +155,21 @@ class Mesh:
     def recalculate_normals(self):
         N.host().rth_mesh_recalculate_normals(self._h); return self
 
-    def generate_sbvh(self):
+    def generate_sbvh(self, device=False):
+        """Mesh::generate_sbvh (mesh.rs:257-272) on the host; device=True leaves the tree to the render library,
+        which builds it on the GPU at upload (no host tree: such a mesh cannot be rendered by a CPU checker)."""
+        if device:
+            N.host().rth_mesh_use_device_bvh(self._h, 1)
+            return self
+        N.host().rth_mesh_use_device_bvh(self._h, 0)
         if N.host().rth_mesh_generate_sbvh(self._h):
+            raise RuntimeError(N.host_error())
+        return self
+
+    def set_verts(self, verts):
+        """new positions for the same connectivity (an animated mesh): count must match"""
+        v = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+        if N.host().rth_mesh_set_verts(self._h, len(v), v.ctypes.data):
             raise RuntimeError(N.host_error())
         return self
 
@@ -269,6 +282,14 @@ class Scene:
             raise TypeError(f"not a scene object: {obj!r}")
         self.n_objects += 1
         return self
+
+    def mesh_at(self, index):
+        """the scene's own copy of the mesh added as object `index` (add() copies): edits through it -- set_verts,
+        recalculate_normals, generate_sbvh -- show in the next flatten()"""
+        h = N.host().rth_scene_object_mesh(self._h, int(index))
+        if not h:
+            raise RuntimeError(N.host_error())
+        return Mesh(_handle=h)
 
     def add_light(self, l):
         H = N.host()

@@ -119,8 +119,9 @@ def cornell_scene(vw=1920, vh=1080):
     return s
 
 
-def sdl_mesh(mesh, position=(0., 0., 0.), scale=1., rotate_xyz=None, rotate_zyx=None, recenter=True):
-    """the mesh pipeline of interpret.rs:822-855"""
+def sdl_mesh(mesh, position=(0., 0., 0.), scale=1., rotate_xyz=None, rotate_zyx=None, recenter=True, device_bvh=False):
+    """the mesh pipeline of interpret.rs:822-855 (device_bvh: the tree is left to the render library, which builds it on
+    the GPU at upload, instead of Mesh::generate_sbvh on the host)"""
     if scale != 1.:
         mesh.scale(scale)
     if recenter:
@@ -133,7 +134,7 @@ def sdl_mesh(mesh, position=(0., 0., 0.), scale=1., rotate_xyz=None, rotate_zyx=
         mesh.shift(position)
     if mesh.n_normals == 0:
         mesh.recalculate_normals()
-    mesh.generate_sbvh()
+    mesh.generate_sbvh(device=device_bvh)
     return mesh
 
 
@@ -164,7 +165,7 @@ def teapot_scene(obj_path, vw=3840, vh=2160, seed=1):
     return s
 
 
-def synthetic_terrain_scene(vw=3840, vh=2160, cells=708, n_lights=8, seed=42):
+def synthetic_terrain_scene(vw=3840, vh=2160, cells=708, n_lights=8, seed=42, device_bvh=False):
     """Config 4: a cells x cells fBm height field (2*cells^2 triangles; 708 ->
     1,002,528), reflective 0.3, one glass sphere above it, `n_lights` point
     lights on a ring, solid skybox, camera looking down ~30 degrees."""
@@ -172,8 +173,9 @@ def synthetic_terrain_scene(vw=3840, vh=2160, cells=708, n_lights=8, seed=42):
     extent = float(cells)
     mesh = Mesh.heightfield(cells, cells, cell=1.0, amplitude=extent * 0.02, base_freq=8.0 / extent, octaves=3, seed=seed,
                             material=sdl_material(Texture.solid((200, 190, 170)), reflectiveness=0.3))
-    sdl_mesh(mesh, position=(0., 0., 0.))           # recentred on the origin
+    sdl_mesh(mesh, position=(0., 0., 0.), device_bvh=device_bvh)           # recentred on the origin
     s.add(mesh)
+    s.mesh = s.mesh_at(0)
     s.add(Sphere((0., extent * 0.06, 0.), extent * 0.04, sdl_material(transparency=0.6, reflectiveness=0.5)))
     s.skybox_solid((30, 40, 70))
     ring_r, ring_h = extent * 0.28, extent * 0.085
@@ -224,7 +226,7 @@ def terrain_scene(vw=7680, vh=4320, w=72, h=72, seed=11, cubemap=None):
     return s
 
 
-def small_mixed_scene(vw=160, vh=120, cells=24, seed=5):
+def small_mixed_scene(vw=160, vh=120, cells=24, seed=5, device_bvh=False):
     """A small scene touching every device code path: mesh (reflective), glass
     sphere (refraction + fresnel mix), see-through box (ior 1), checker plane,
     emissive box, sun + two point lights, cubemap skybox."""
@@ -236,8 +238,9 @@ def small_mixed_scene(vw=160, vh=120, cells=24, seed=5):
     s.add_light(Point(position=(-4., 3., 1.), intensity=5., color=(255, 200, 160)))
     mesh = Mesh.heightfield(cells, cells, cell=0.5, amplitude=0.6, base_freq=0.3, octaves=3, seed=seed,
                             material=sdl_material(Texture.solid((180, 200, 160)), reflectiveness=0.3))
-    sdl_mesh(mesh, position=(0., -0.5, 0.))
+    sdl_mesh(mesh, position=(0., -0.5, 0.), device_bvh=device_bvh)
     s.add(mesh)
+    s.mesh = s.mesh_at(0)
     s.add(sdl_plane((0., -2., 0.), material=sdl_material(Texture.checkerboard((255, 255, 255), (60, 60, 60)), reflectiveness=0.2), uv_wrap=2.))
     s.add(Sphere((0., 1.5, 1.), 1., sdl_material(transparency=0.6, reflectiveness=0.5)))
     s.add(Sphere((-2.5, 1.0, 0.), 0.8, sdl_material(Texture.solid((255, 40, 40)), reflectiveness=0.4)))

@@ -675,3 +675,55 @@ def test_full_size_configs_sampled_and_properties(name, sample):
         ctx.detile(gathered.data_ptr(), 8, slots, 3, frame.data_ptr())
         assert np.array_equal(frame.cpu().numpy().reshape(vh, vw, 3), rgb)
         assert rays == st.rays
+
+
+@pytest.mark.parametrize("builder,args", [
+    (scenes.synthetic_terrain_scene, (256, 144, 48)),
+    (scenes.small_mixed_scene, (200, 150, 16)),
+    (scenes.synthetic_terrain_scene, (640, 360, 300)),
+])
+def test_tree_built_on_the_device_gives_the_host_trees_frame(builder, args):
+    """rt_mesh::nodes == NULL: the library builds the mesh's tree itself (linear BVH on the device).  What a ray hits
+    does not depend on the tree; the frame must be the host-built (reference-topology) tree's frame, which is the
+    oracle's."""
+    host = builder(*args)
+    dev = builder(*args, device_bvh=True)
+    with ra.Context(0) as ctx:
+        ctx.upload(host)
+        r0, i0, s0 = ctx.render(ids=True)
+        ctx.upload(dev)
+        r1, i1, s1 = ctx.render(ids=True)
+        r2, i2, s2 = ctx.render(ids=True)
+    assert np.array_equal(r1, r2) and np.array_equal(i1, i2)
+    assert ray_counts(s0) == ray_counts(s1)
+    assert id_match(i1, i0) >= ID_BAR                 # (ties between two triangles hit at the same distance may differ)
+    assert image_metrics(r1, r0)["exact"] >= 0.9999
+    if args[0] * args[1] <= 40000:
+        o_rgb, o_ids, _, _ = oracle.render(host, 0)
+        assert_parity(r1, i1, o_rgb, o_ids, exact_floor=0.9999)
+
+
+def test_refit_after_the_vertices_moved():
+    """rt_mesh::unchanged == 2: same connectivity, same tree, new vertex positions and normals: boxes and triangle records
+    are recomputed on the device.  The frame equals that of a scene built from scratch with the moved vertices, for a
+    host-built tree and for a device-built one."""
+    for device_bvh in (False, True):
+        s = scenes.synthetic_terrain_scene(320, 180, cells=64, device_bvh=device_bvh)
+        fresh = scenes.synthetic_terrain_scene(320, 180, cells=64)
+        v = s.mesh.verts
+        moved = v.copy()
+        moved[:, 1] += 0.8 * np.sin(v[:, 0] * 0.4) * np.cos(v[:, 2] * 0.3)
+        with ra.Context(0) as ctx:
+            ctx.upload(s)
+            before = ctx.render()[0]
+            s.mesh.set_verts(moved).recalculate_normals()
+            ctx.upload(s, keep_meshes="refit")
+            got, got_ids, st = ctx.render(ids=True)
+            fresh.mesh.set_verts(moved).recalculate_normals().generate_sbvh()
+            ctx.upload(fresh)
+            want, want_ids, st2 = ctx.render(ids=True)
+        assert not np.array_equal(before, got)
+        assert ray_counts(st) == ray_counts(st2)
+        assert id_match(got_ids, want_ids) >= ID_BAR and image_metrics(got, want)["exact"] >= 0.9999
+        o_rgb, o_ids, _, _ = oracle.render(fresh, 0)
+        assert_parity(got, got_ids, o_rgb, o_ids, exact_floor=0.9999)
