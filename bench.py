@@ -11,10 +11,10 @@ gathered to rank 0 (RCCL) and scattered into the row-major frame (rt_detile).  T
 timed region; the frame stays in HBM.  A ray is one Scene::cast_ray_once call of the reference.
 
 The K timed frames are a sequence (the reference's --sequence workload): --frames-in-flight F sets of launches (default
-4 on one GPU, 2 when the frame is sharded) are in flight per GPU, each frame complete and delivered in order; F = 1
-renders them strictly one after the other.  When the frame is sharded over N GPUs a set of launches covers this rank's
-shard of --batch B = N consecutive frames (rt_render_shard_batch), which keeps the launches as large as a whole
-frame's.  The line also carries the one-frame-at-a-time figure (`ms_per_frame_alone`) and, on one GPU, the time per
+3 on one GPU, 2 when the frame is sharded) are in flight per GPU, each frame complete and delivered in order; F = 1
+renders them strictly one after the other.  A set of launches covers --batch B consecutive frames (rt_render_shard_batch):
+2 whole frames on one GPU, and this rank's shard of N frames when the frame is sharded over N GPUs, which keeps the
+launches as large as a whole frame's.  The line also carries the one-frame-at-a-time figure (`ms_per_frame_alone`) and, on one GPU, the time per
 frame through rt_render, host pixels included (`ms_per_frame_end_to_end`).
 
 Roofline of the dominant kernel (the budget-free shadow packet kernel, k_shadow<false, false>): its launches are timed
@@ -185,11 +185,12 @@ def main():
     # One GPU, whole frame: 4 frames in flight.  A 1/N shard's launches are N times smaller and fill the chip badly
     # (a 1/8 shard takes 1.7-2.4 ms per frame however many are in flight, against 1.35 for an eighth of a whole frame);
     # N consecutive frames per set of launches restore their size, and two such sets in flight hide the tails.
+    small = vw * vh <= 3840 * 2160          # (an 8K frame's wavefront levels take tens of GB per frame in flight)
     if args.batch is None:
-        args.batch = 1 if world == 1 else min(world, 8)
+        # two whole frames per set of launches, three sets in flight: 3-4 % more frames per second than four single frames
+        args.batch = (2 if small else 1) if world == 1 else min(world, 8)
     if args.frames_in_flight is None:
-        # (an 8K frame's wavefront levels take tens of GB per frame in flight)
-        args.frames_in_flight = 4 if args.batch == 1 and vw * vh <= 3840 * 2160 else 2
+        args.frames_in_flight = (3 if args.batch > 1 else 4) if world == 1 and small else 2
     depth, batch = max(1, args.frames_in_flight), max(1, args.batch)
     pipe = rd.FramePipeline(make_context, rank, world, device, depth=depth, batch=batch)
     t_upload = t_upload[0]

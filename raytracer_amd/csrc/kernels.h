@@ -198,15 +198,19 @@ DEV void load_hit(const DLevel& L, uint32_t i, const Ray& ray, Hit& h) {
 // BUDGET: the lane-by-lane walks give up after lp.budget_lane inner nodes (a separate variant: the bookkeeping costs
 // registers and time, and few scenes have rays that need it).
 // FAR: see cast_closest_packet.
-// (asked to fit 4 waves per SIMD: the allocator then finds 118 registers enough, without spills, where it takes 156
-// when left alone)
+// (the lane-by-lane variants are asked to fit 4 waves per SIMD: the allocator then finds 118 registers enough, without
+// spills, where it takes 156 when left alone; at 5 waves they spill and are 15 % slower.  The packet variants hold most
+// of their state in scalar registers and LDS and gain 10 % from a fifth wave.)
 #ifndef RT_TRACE_ATTR
 #define RT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(4, 8)))
 #endif
+#ifndef RT_TRACE_PACKET_ATTR
+#define RT_TRACE_PACKET_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
+#endif
 // MESHES = false: a scene of analytic objects only (lane by lane, no budget): the mesh walks stay out of the kernel.
-template <bool COUNT, bool PACKET, bool BUDGET, bool FAR = true, bool MESHES = true>
-__global__ __launch_bounds__(RT_BLOCK) RT_TRACE_ATTR void k_trace(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, uint32_t* hitlist, double* hs, uint32_t stride,
-                                                    DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
+template <bool COUNT, bool PACKET, bool BUDGET, bool FAR, bool MESHES>
+DEV void trace_body(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, uint32_t* hitlist, double* hs, uint32_t stride,
+                    DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     n = level_size(n, n_dev);
     if (blockIdx.x * RT_BLOCK >= n) return;   // (a whole workgroup past the end: launches are sized for the level's room)
@@ -238,6 +242,17 @@ __global__ __launch_bounds__(RT_BLOCK) RT_TRACE_ATTR void k_trace(const DScene* 
         block_count3(vc.nodes, vc.tris, vc.units, &sh->nodes_visited, &sh->tris_tested, &sh->units_fetched);
         block_count3(lane_id() == 0 ? vc.wnodes : 0, lane_id() == 0 ? vc.wtris : 0, 0, &sh->wave_nodes, &sh->wave_tris, nullptr);
     }
+}
+template <bool COUNT, bool PACKET, bool BUDGET, bool FAR = true, bool MESHES = true>
+__global__ __launch_bounds__(RT_BLOCK) RT_TRACE_ATTR void k_trace(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, uint32_t* hitlist, double* hs, uint32_t stride,
+                                                    DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
+    static_assert(!PACKET, "the packet variants are k_trace_packet");
+    trace_body<COUNT, false, BUDGET, FAR, MESHES>(Sp, L, n, n_dev, hitlist, hs, stride, C, LC, longlist, lp);
+}
+template <bool COUNT, bool FAR>
+__global__ __launch_bounds__(RT_BLOCK) RT_TRACE_PACKET_ATTR void k_trace_packet(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, uint32_t* hitlist, double* hs, uint32_t stride,
+                                                    DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
+    trace_body<COUNT, true, false, FAR, true>(Sp, L, n, n_dev, hitlist, hs, stride, C, LC, longlist, lp);
 }
 
 // The listed long rays of a level, RT_SEGS lanes each: lane k walks piece k of the ray through every mesh, the

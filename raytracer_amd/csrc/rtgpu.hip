@@ -747,8 +747,8 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
             const bool cnt = (c->count_visits & 1) != 0;
             if (c->hscene.n_meshes == 0) { if (cnt) launch(k_trace<true, false, false, false, false>); else launch(k_trace<false, false, false, false, false>); }
             else if (depth <= c->packet_depth) {   // (packets pay for mesh walks only)
-                if (c->any_need_far) { if (cnt) launch(k_trace<true, true, false, true>); else launch(k_trace<false, true, false, true>); }
-                else { if (cnt) launch(k_trace<true, true, false, false>); else launch(k_trace<false, true, false, false>); }
+                if (c->any_need_far) { if (cnt) launch(k_trace_packet<true, true>); else launch(k_trace_packet<false, true>); }
+                else { if (cnt) launch(k_trace_packet<true, false>); else launch(k_trace_packet<false, false>); }
             }
             else if (lp.budget_lane) { if (cnt) launch(k_trace<true, false, true>); else launch(k_trace<false, false, true>); }
             else if (c->any_need_far) { if (cnt) launch(k_trace<true, false, false, true>); else launch(k_trace<false, false, false, true>); }
