@@ -68,12 +68,14 @@ DEV void pray_axis(double o, double m, float B, float& mf, float& cmin, float& c
 }
 // The same from the direction itself, without the f64 division: 1/direction as the f32 reciprocal (1 ulp) of the
 // direction rounded to f32, so the slope is off by up to 3 * 2^-24 instead of 2^-24 and the total by 5 * 2^-24
-// (|o| + B) |m|: the slack is 2^-21.
+// (|o| + B) |m|; c is rounded to nearest (that rounding is the first term above) and c -+ slack rounds once more,
+// 6 * 2^-24 in all: the slack is 9 * 2^-24.  (Directed roundings of c would be a dozen instructions each here, and
+// these constants are worked out again after every round of triangle tests.)
 DEV void pray_axis_d(double o, double d, float B, float& mf, float& cmin, float& cmax) {
     mf = fminf(fmaxf(__builtin_amdgcn_rcpf((float)d), -1e30f), 1e30f);
-    const double om = o * (double)mf;
-    const float slack = (fabsf((float)o) + B) * fabsf(mf) * 4.8e-7f;   // 2^-21, rounded up
-    const float lo = __double2float_rd(-om) - slack, hi = __double2float_ru(-om) + slack;
+    const float c = (float)-(o * (double)mf);
+    const float slack = (fabsf((float)o) + B) * fabsf(mf) * 5.4e-7f;   // 9 * 2^-24, rounded up
+    const float lo = c - slack, hi = c + slack;
     const bool pos = !(mf < 0.f);
     cmin = pos ? lo : hi;
     cmax = pos ? hi : lo;
@@ -138,7 +140,7 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
     mh.n = 0; mh.t0 = bound; mh.t1 = bound; mh.r0 = 0;
     const DNode* nodes = uni_ptr(Mg.nodes);
     const DTri* tris = uni_ptr(Mg.tris);
-    float limit = __double2float_ru(bound);
+    float limit = limit_up(bound);
     const PRay pr = pray_new(ray, asf(uni(__float_as_uint(Mg.coord_max))));
 
     float tn_root;
@@ -161,7 +163,7 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
                 if (__lane_id() == 0) vc.units += 5;
                 if (in && tri_test(T, ray, t, u, v) && (t < mh.t0 || (t == mh.t0 && rank < mh.r0))) {
                     mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v; mh.n = 1;
-                    limit = __double2float_ru(t);
+                    limit = limit_up(t);
                 }
                 if (T.last) break;
                 ++rank;
@@ -224,6 +226,14 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
 __shared__ double rt_qray[RT_PWAVES * 6 * 64];                // [wave][o.x o.y o.z d.x d.y d.z][lane]
 __shared__ unsigned long long rt_qbound[RT_PWAVES * 64];      // bits of the lane's distance limit, + 1; 0 = blocked / no ray
 __shared__ uint32_t rt_qpair[RT_PWAVES * RT_QCAP];
+// (lane, inner node) pairs: the thin ends of the walk, see node_pairs()
+#ifndef RT_SPARSE
+#define RT_SPARSE 16    /* a child entered by at most this many lanes leaves the packet walk */
+#endif
+#ifndef RT_NCAP
+#define RT_NCAP 224
+#endif
+__shared__ uint32_t rt_qnode[RT_PWAVES * RT_NCAP];
 
 DEV bool in_mask(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }   // this lane's bit, for free
 DEV uint32_t lanes_below(unsigned long long mask) {   // set bits of mask below this lane
@@ -305,6 +315,64 @@ __device__ void test_pairs(const DTri* tris, uint32_t base, uint32_t cnt, Visits
     wave_lds_sync();
 }
 
+// The thin ends of the walk.  Near the leaves the lanes of a packet have gone separate ways: half of a terrain's node
+// steps serve fewer than 16 of the 64 lanes, a quarter fewer than 4, and a step costs the wave the same whatever the
+// number.  So a child that few lanes entered is not walked by the packet: its (lane, node) pairs wait in a second
+// queue, and a round of node tests gives every lane of the wave one pair -- that ray from LDS, that node's record
+// by vector loads, the same box arithmetic (entry and exit found per slab by min/max instead of by the octant, to
+// the same values) -- and files the children entered as new pairs: leaves with the triangle pairs, inner nodes back
+// here.  The newest pairs go first (depth first), which keeps the queue short.
+// p = pairs to take (from the end of the queue); pn, qn = fill of the node and the triangle queue.
+__device__ void node_pairs(const DNode* nodes, float coord_max, uint32_t p, uint32_t& pn, uint32_t& qn, Visits& vc) {
+    const uint32_t w = uni(threadIdx.x >> 6), l = lane_now();
+    const uint32_t wq = w * RT_QCAP, wn = w * RT_NCAP;
+    wave_lds_sync();
+    pn -= p;
+    bool h0 = false, h1 = false, h2 = false, h3 = false;
+    uint32_t owner = 0;
+    rt_u4 ref; ref.x = ref.y = ref.z = ref.w = RT_NO_CHILD;
+    vc.wnodes++;
+    if (l < p) {
+        const uint32_t e = rt_qnode[wn + pn + l];
+        owner = e & 63u;
+        const unsigned long long b = rt_qbound[w * 64 + owner];
+        if (b != 0) {
+            const double* qr = rt_qray + w * 6 * 64 + owner;
+            PRay pr;
+            pray_axis_d(qr[0], qr[192], coord_max, pr.mx, pr.cminx, pr.cmaxx);
+            pray_axis_d(qr[64], qr[256], coord_max, pr.my, pr.cminy, pr.cmaxy);
+            pray_axis_d(qr[128], qr[320], coord_max, pr.mz, pr.cminz, pr.cmaxz);
+            const float limit = b > 1 ? limit_up(__longlong_as_double((long long)(b - 1ull))) : 0.f;
+            const RT_GLOBAL rt_u4* rec = (const RT_GLOBAL rt_u4*)(gptr(nodes) + (e >> 6));
+            UNode n;
+            n.minx = rec[0]; n.miny = rec[1]; n.minz = rec[2]; n.maxx = rec[3]; n.maxy = rec[4]; n.maxz = rec[5]; ref = rec[6];
+            vc.nodes++; vc.units += 7;
+            float t0, t1, t2, t3, f0, f1, f2, f3;
+            RT_CHILD_PAIR(n, 0, t0, f0, t1, f1);
+            RT_CHILD_PAIR(n, 2, t2, f2, t3, f3);
+            h0 = fmaxf(t0, 0.f) <= fminf(f0, limit);
+            h1 = fmaxf(t1, 0.f) <= fminf(f1, limit);
+            h2 = fmaxf(t2, 0.f) <= fminf(f2, limit) && ref.z != RT_NO_CHILD;
+            h3 = fmaxf(t3, 0.f) <= fminf(f3, limit) && ref.w != RT_NO_CHILD;
+        }
+    }
+#define RT_PAIR_CHILD(h_, r_)                                                                              \
+    {                                                                                                      \
+        const unsigned long long mh_ = __ballot(h_), leaf_ = __ballot((int)(r_) < 0);                      \
+        const unsigned long long ml_ = mh_ & leaf_, mi_ = mh_ & ~leaf_;                                    \
+        if (in_mask(ml_)) rt_qpair[wq + qn + lanes_below(ml_)] = (((r_) & ~RT_LEAF_BIT) << 6) | owner;     \
+        qn += (uint32_t)__popcll(ml_);                                                                     \
+        if (in_mask(mi_)) rt_qnode[wn + pn + lanes_below(mi_)] = ((r_) << 6) | owner;                      \
+        pn += (uint32_t)__popcll(mi_);                                                                     \
+    }
+    RT_PAIR_CHILD(h3, ref.w)
+    RT_PAIR_CHILD(h2, ref.z)
+    RT_PAIR_CHILD(h1, ref.y)
+    RT_PAIR_CHILD(h0, ref.x)
+#undef RT_PAIR_CHILD
+    wave_lds_sync();
+}
+
 // The shadow walk of one mesh for the parked rays.  Every lane of the wave must call it.  Lanes found blocked have
 // their bound word cleared.  With BUDGET the wave gives up after `budget` inner nodes and reports the lanes that
 // were still open in `unresolved` (their rays are then finished piecewise by other lanes, mesh_traverse_seg);
@@ -319,7 +387,7 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
     const DNode* nodes = Mg.nodes;
     const DTri* tris = Mg.tris;
     const uint32_t w = uni(threadIdx.x >> 6);
-    const uint32_t wq = w * RT_QCAP;
+    const uint32_t wq = w * RT_QCAP, wn = w * RT_NCAP;
     // Per-lane constants of the box test, as in PRay but filed by role: c_entry goes with the plane the ray meets
     // first along the axis, c_exit with the other.  Which plane that is (min or max) depends on the direction's sign
     // only, and the walk below handles lanes of one sign pattern at a time, so it is settled per walk, not per test.
@@ -339,7 +407,7 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
         pray_axis_d(qr_[64], qr_[256], B_, k.my, lo_, hi_); k.eny = fminf(lo_, hi_); k.exy = fmaxf(lo_, hi_);
         pray_axis_d(qr_[128], qr_[320], B_, k.mz, lo_, hi_); k.enz = fminf(lo_, hi_); k.exz = fmaxf(lo_, hi_);
         // b - 1 = the bits of the bound, or 0 (a bound that cannot be met: the box distance limit 0 is as good as any)
-        k.limit = b_ > 1 ? __double2float_ru(__longlong_as_double((long long)(b_ - 1ull))) : 0.f;
+        k.limit = b_ > 1 ? limit_up(__longlong_as_double((long long)(b_ - 1ull))) : 0.f;
         return k;
     };
     unsigned long long remaining;
@@ -359,16 +427,21 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
     }
     if (!remaining) return;
     const uint32_t root = Mg.root_ref;
-    uint32_t qn = 0;
+    uint32_t qn = 0, pn = 0;
     RStack st; st.ref = 0; st.lo = 0; st.hi = 0; st.sp = 0;
     unsigned long long alive = 0;
 
-    // a child some lane entered: a leaf's (lane, leaf) pairs go on the queue, an inner node on the stack
+    // a child some lane entered: a leaf's (lane, leaf) pairs go on the triangle queue, an inner node on the stack,
+    // or, entered by few lanes (and while there is room), on the node queue
 #define RT_CHILD_ENTERED(r_, m_)                                                                    \
     if (m_) {                                                                                       \
+        const uint32_t c_ = (uint32_t)__popcll(m_);                                                 \
         if ((r_) & RT_LEAF_BIT) {                                                                   \
             if (in_mask(m_)) rt_qpair[wq + qn + lanes_below(m_)] = (((r_) & ~RT_LEAF_BIT) << 6) | lane_now(); \
-            qn += (uint32_t)__popcll(m_);                                                           \
+            qn += c_;                                                                               \
+        } else if (c_ <= RT_SPARSE && pn + c_ <= RT_NCAP) {                                         \
+            if (in_mask(m_)) rt_qnode[wn + pn + lanes_below(m_)] = ((r_) << 6) | lane_now();        \
+            pn += c_;                                                                               \
         } else st.push((r_), (m_));                                                                 \
     }
     // children k and k+1: entry distance = the latest of the three entry planes, exit = the earliest exit plane
@@ -396,7 +469,7 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
         const uint32_t i_en_x = (octant & 1u) ? 3u : 0u, i_ex_x = (octant & 1u) ? 0u : 3u;
         const uint32_t i_en_y = (octant & 2u) ? 4u : 1u, i_ex_y = (octant & 2u) ? 1u : 4u;
         const uint32_t i_en_z = (octant & 4u) ? 5u : 2u, i_ex_z = (octant & 4u) ? 2u : 5u;
-        qn = 0;   // (pairs left over from a group whose lanes are all blocked)
+        qn = 0; pn = 0;   // (pairs left over from a group whose lanes are all blocked)
         st.sp = 0;
         if (root & RT_LEAF_BIT) {
             // a mesh of one leaf: nothing to walk, every lane of the group takes the leaf to the triangle rounds
@@ -404,15 +477,43 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
             qn = (uint32_t)__popcll(alive);
         } else st.push(root, alive);
         while (true) {
-            // one stretch of the walk: until 48 pairs wait or nothing is left to walk
-            if (st.sp > 0 && qn < RT_QFLUSH) {
+            if (qn >= RT_QFLUSH || (qn > 0 && st.sp == 0 && pn == 0)) {
+                // one round of triangle tests (the one place where triangles are tested, so that the kernel holds that
+                // code once): when 48 pairs wait, or nothing else is left to do
+                const uint32_t cnt = qn < 64 ? qn : 64;
+                qn -= cnt;
+                test_pairs(tris, qn, cnt, vc);
+                alive &= ~__ballot(parked_blocked());
+                if (!alive) break;
+                continue;
+            }
+            if (pn >= 64 || (pn > 0 && st.sp == 0)) {
+                // one round of node tests: when 64 pairs wait, or the packet has nothing left to walk.  A round may
+                // add three pairs for every one it takes, so a queue that is nearly full takes fewer; a full one hands
+                // its newest pair back to the packet walk (whose stack is bounded by the tree's depth).
+                if (BUDGET && ++steps > budget) { unresolved = 1; break; }
+                uint32_t p = pn < 64 ? pn : 64;
+                const uint32_t room = (RT_NCAP - pn) / 3;
+                if (room < p) p = room;
+                if (p == 0) {
+                    const uint32_t e = uni(rt_qnode[wn + pn - 1]);
+                    --pn;
+                    st.push(e >> 6, 1ull << (e & 63u));
+                } else {
+                    node_pairs(nodes, Mg.coord_max, p, pn, qn, vc);
+                    continue;
+                }
+            }
+            if (st.sp == 0) break;   // (and both queues are empty)
+            // one stretch of the packet walk: until a queue wants a round or nothing is left to walk
+            {
                 const BoxK K = box_constants();
                 do {
                     const unsigned long long inmask = st.top_mask() & alive;
                     const uint32_t cur = st.top_ref();
                     --st.sp;
                     if (!inmask) continue;   // everybody who wanted this node has been blocked since
-                    if (BUDGET && ++steps > budget) { unresolved = 1; st.sp = 0; break; }
+                    if (BUDGET && ++steps > budget) { unresolved = 1; st.sp = 0; qn = 0; pn = 0; break; }
                     const RT_CONST rt_u4* rec = (const RT_CONST rt_u4*)(nodes + cur);
                     const rt_u4 pen_x = rec[i_en_x], pex_x = rec[i_ex_x], pen_y = rec[i_en_y], pex_y = rec[i_ex_y];
                     const rt_u4 pen_z = rec[i_en_z], pex_z = rec[i_ex_z], ref = rec[6];
@@ -431,16 +532,8 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
                     RT_CHILD_ENTERED(ref[2], m2)
                     RT_CHILD_ENTERED(ref[1], m1)
                     RT_CHILD_ENTERED(ref[0], m0)   // pushed last: walked first (the order makes no measurable difference)
-                } while (st.sp > 0 && qn < RT_QFLUSH);
+                } while (st.sp > 0 && qn < RT_QFLUSH && pn < 64);
             }
-            if (qn == 0) break;
-            // one round of triangle tests (the one place where triangles are tested, so that the kernel holds that
-            // code once); the walk goes on afterwards unless more than a round's worth still waits
-            const uint32_t cnt = qn < 64 ? qn : 64;
-            qn -= cnt;
-            test_pairs(tris, qn, cnt, vc);
-            alive &= ~__ballot(parked_blocked());
-            if (!alive) break;
         }
         if (BUDGET && unresolved) { unresolved = alive | remaining; break; }   // out of budget: the lanes still open
     }

@@ -33,6 +33,11 @@ template <typename P> DEV D3 ld3(P p) { return d3(p[0], p[1], p[2]); }
 DEV double signum(double x) { return x != x ? x : copysign(1.0, x); }
 // Rust f64::clamp: NaN stays NaN
 DEV double clampd(double x, double lo, double hi) { if (x < lo) x = lo; if (x > hi) x = hi; return x; }
+// a distance limit as f32, not below the f64 value: rounded to nearest, then moved up by more than that rounding
+DEV float limit_up(double b) {
+    const float f = (float)b;
+    return fmaf(fabsf(f), 1.2e-7f, f) + 1.1754944e-38f;
+}
 DEV float clampf(float x, float lo, float hi) { if (x < lo) x = lo; if (x > hi) x = hi; return x; }
 // Rust `as u8` / `as u32`: truncation toward zero, saturating, NaN -> 0
 DEV uint32_t as_u8(double v) { if (!(v > 0.0)) return 0u; if (v >= 255.0) return 255u; return (uint32_t)(int)v; }
@@ -342,7 +347,7 @@ __device__ bool mesh_traverse_seg(const DMesh& M, const Ray& ray, double bound, 
     const GTriPtr tris = gptr(M.tris);
     uint32_t cur = M.root_ref;
     // boxes entered beyond `limit` cannot hold the answer; kept in f32, rounded up so that the skip stays safe
-    float limit = __double2float_ru(bound);
+    float limit = limit_up(bound);
     const float INF = __uint_as_float(0x7F800000u);
 
     while (cur != RT_POP) {
@@ -412,14 +417,14 @@ __device__ bool mesh_traverse_seg(const DMesh& M, const Ray& ray, double bound, 
                 } else if (MODE == TRAV_CLOSEST) {
                     if (t < mh.t0 || (t == mh.t0 && rank < mh.r0)) {
                         mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v; mh.n = 1;
-                        limit = __double2float_ru(t);
+                        limit = limit_up(t);
                     }
                 } else {
                     if (mh.n == 0 || t < mh.t0 || (t == mh.t0 && rank < mh.r0)) {
                         if (mh.n >= 1) { mh.t1 = mh.t0; mh.n = 2; } else mh.n = 1;
                         mh.t0 = t; mh.r0 = rank; mh.u = u; mh.v = v;
                     } else if (mh.n == 1 || t < mh.t1) { mh.t1 = t; mh.n = 2; }
-                    if (mh.n == 2) limit = __double2float_ru(mh.t1);
+                    if (mh.n == 2) limit = limit_up(mh.t1);
                 }
             }
             if (last) break;
@@ -448,7 +453,7 @@ DEV Seg mesh_segment(const DMesh& M, const Ray& ray, double bound, uint32_t k, u
     float tn, tf;
     Seg sg; sg.lo = -INF; sg.hi = INF; sg.budget = 0;
     if (!node_box2(M.root_min, M.root_max, ray, tn, tf)) return sg;   // the walk returns at its own root test
-    const float a = fmaxf(tn, 0.f), b = fminf(tf, __double2float_ru(bound));
+    const float a = fmaxf(tn, 0.f), b = fminf(tf, limit_up(bound));
     if (!(b > a)) return sg;
     const float step = (b - a) / (float)K;
     if (k > 0) sg.lo = a + step * (float)k;
@@ -533,7 +538,7 @@ __device__ bool tlas_closest(const DScene& S, const Ray& ray, Closest& c, bool a
     for (uint32_t i = 0; i < n;) {
         const RT_GLOBAL DTlasNode* nd = nodes + i;
         float tn;
-        if (cull && !(node_box(nd->bmin, nd->bmax, ray, tn) && !(any && tn > __double2float_ru(c.t)))) { i = nd->skip; continue; }
+        if (cull && !(node_box(nd->bmin, nd->bmax, ray, tn) && !(any && tn > limit_up(c.t)))) { i = nd->skip; continue; }
         const uint32_t oi = nd->object;
         if (!(oi & RT_TLAS_INNER)) {
             double near;
@@ -602,7 +607,7 @@ __device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c
     const float INF = __uint_as_float(0x7F800000u);
     int sp = 0;
     volatile unsigned long long spill[RT_MAX_STACK - RT_LDS_STACK];
-    float limit = any ? __double2float_ru(c.t) : INF;
+    float limit = any ? limit_up(c.t) : INF;
     float tn_root = -INF;
     if (cull && !(node_box(nodes[0].bmin, nodes[0].bmax, ray, tn_root) && !(tn_root > limit))) return any;
     // an object reached through a leaf reference: nearest by `near`, ties to the lower index
@@ -610,7 +615,7 @@ __device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c
         double near;
         if (tlas_leaf_near(S, what, ray, near) && (!any || near < c.t || (near == c.t && oi < c.obj))) {
             c.obj = oi; c.rank = RT_NONE; c.t = near; c.t2 = 0.; c.u = 0.f; c.v = 0.f; any = true;
-            limit = __double2float_ru(near);
+            limit = limit_up(near);
         }
     };
     uint32_t cur = 0;
@@ -783,7 +788,7 @@ __device__ bool tlas_any_ordered(const DScene& S, const Ray& ray, bool limited, 
     const float INF = __uint_as_float(0x7F800000u);
     int sp = 0;
     volatile unsigned long long spill[RT_MAX_STACK - RT_LDS_STACK];
-    const float limit = limited ? __double2float_ru(dist) : INF;
+    const float limit = limited ? limit_up(dist) : INF;
     float tn_root = -INF;
     if (cull && !(node_box(nodes[0].bmin, nodes[0].bmax, ray, tn_root) && !(tn_root > limit))) return false;
     uint32_t cur = 0;
