@@ -233,6 +233,9 @@ __shared__ uint32_t rt_qpair[RT_PWAVES * RT_QCAP];
 #ifndef RT_NCAP
 #define RT_NCAP 224
 #endif
+#ifndef RT_NFLUSH
+#define RT_NFLUSH 48    /* node pairs waiting at which the packet walk stops for a round of node tests */
+#endif
 __shared__ uint32_t rt_qnode[RT_PWAVES * RT_NCAP];
 
 DEV bool in_mask(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }   // this lane's bit, for free
@@ -487,7 +490,7 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
                 if (!alive) break;
                 continue;
             }
-            if (pn >= 64 || (pn > 0 && st.sp == 0)) {
+            if (pn >= RT_NFLUSH || (pn > 0 && st.sp == 0)) {
                 // one round of node tests: when 64 pairs wait, or the packet has nothing left to walk.  A round may
                 // add three pairs for every one it takes, so a queue that is nearly full takes fewer; a full one hands
                 // its newest pair back to the packet walk (whose stack is bounded by the tree's depth).
@@ -532,7 +535,7 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
                     RT_CHILD_ENTERED(ref[2], m2)
                     RT_CHILD_ENTERED(ref[1], m1)
                     RT_CHILD_ENTERED(ref[0], m0)   // pushed last: walked first (the order makes no measurable difference)
-                } while (st.sp > 0 && qn < RT_QFLUSH && pn < 64);
+                } while (st.sp > 0 && qn < RT_QFLUSH && pn < RT_NFLUSH);
             }
         }
         if (BUDGET && unresolved) { unresolved = alive | remaining; break; }   // out of budget: the lanes still open
