@@ -118,6 +118,17 @@ DEV unsigned long long box_lanes(float tn, float tf, float limit) {
         }                                                                     \
     } while (0)
 
+// the same with each lane's own value t of the two children following along
+#define RT_UCSWAP_T(ka, ra, ma, ta, kb, rb, mb, tb)                           \
+    do {                                                                      \
+        if ((kb) < (ka)) {                                                    \
+            const float k_ = (ka); (ka) = (kb); (kb) = k_;                    \
+            const uint32_t r_ = (ra); (ra) = (rb); (rb) = r_;                 \
+            const unsigned long long m_ = (ma); (ma) = (mb); (mb) = m_;       \
+            const float t_ = (ta); (ta) = (tb); (tb) = t_;                    \
+        }                                                                     \
+    } while (0)
+
 struct PStack {
     rt_u4* base;   // this wave's entries
     int sp;        // uniform
@@ -237,6 +248,11 @@ __shared__ uint32_t rt_qpair[RT_PWAVES * RT_QCAP];
 #define RT_NFLUSH 48    /* node pairs waiting at which the packet walk stops for a round of node tests */
 #endif
 __shared__ uint32_t rt_qnode[RT_PWAVES * RT_NCAP];
+// closest-hit walks only: the entry distance of each queued node pair (a pair whose node lies beyond the ray's best
+// hit by the time its turn comes is dropped unread), and per ray the best hit's triangle and barycentrics
+__shared__ float rt_qntn[RT_PWAVES * RT_NCAP];
+__shared__ uint32_t rt_qrank[RT_PWAVES * 64];
+__shared__ float2 rt_quv[RT_PWAVES * 64];
 
 DEV bool in_mask(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }   // this lane's bit, for free
 DEV uint32_t lanes_below(unsigned long long mask) {   // set bits of mask below this lane
@@ -285,6 +301,18 @@ DEV void park_rays(const Ray& ray, bool active, double bound) {
     rt_qbound[w * 64 + l] = b;
     wave_lds_sync();
 }
+// The same for a closest-hit walk: the bound word holds the bits of the best distance so far (hits must be nearer,
+// or as near with a lower triangle position: the outside bound enters with position 0, which nothing beats);
+// 0 = no ray.
+DEV void park_rays_closest(const Ray& ray, bool active, double bound) {
+    const uint32_t w = uni(threadIdx.x >> 6), l = lane_now();
+    double* qr = rt_qray + w * 6 * 64;
+    qr[l] = ray.o.x; qr[64 + l] = ray.o.y; qr[128 + l] = ray.o.z;
+    qr[192 + l] = ray.d.x; qr[256 + l] = ray.d.y; qr[320 + l] = ray.d.z;
+    rt_qbound[w * 64 + l] = active && bound > 0. ? (unsigned long long)__double_as_longlong(bound) : 0ull;
+    rt_qrank[w * 64 + l] = 0;
+    wave_lds_sync();
+}
 DEV bool parked_blocked() { return rt_qbound[uni(threadIdx.x >> 6) * 64 + lane_now()] == 0; }   // (one word per thread of the block)
 
 // One batch: lane k takes pair base + k (k < cnt).
@@ -318,6 +346,65 @@ __device__ void test_pairs(const DTri* tris, uint32_t base, uint32_t cnt, Visits
     wave_lds_sync();
 }
 
+// the f32 distance limit of a bound word (never below the bound itself)
+template <bool CLOSEST>
+DEV float bound_limit(unsigned long long b) {
+    if (CLOSEST) return limit_up(__longlong_as_double((long long)b));
+    // b - 1 = the bits of the bound, or 0 (a bound that cannot be met: the box distance limit 0 is as good as any)
+    return b > 1 ? limit_up(__longlong_as_double((long long)(b - 1ull))) : 0.f;
+}
+
+// One batch of a closest-hit walk: lane k takes pair base + k and finds the best hit among its leaf's triangles that
+// beats the owner's best; then the lanes that worked for one owner settle it between them in LDS: the nearest
+// distance by an atomic minimum on the bound word (positive doubles order like their bit patterns), among equals
+// the lowest triangle position by a second minimum, and the winner files its barycentrics.
+__device__ void test_pairs_closest(const DTri* tris, uint32_t base, uint32_t cnt, Visits& vc) {
+    const uint32_t w = uni(threadIdx.x >> 6), l = lane_now();
+    const double* qr = rt_qray + w * 6 * 64;
+    unsigned long long* qb = rt_qbound + w * 64;
+    uint32_t* qk = rt_qrank + w * 64;
+    wave_lds_sync();
+    vc.wtris++;
+    bool found = false;
+    uint32_t owner = 0, brank = 0;
+    unsigned long long b = 0, bt = 0;
+    float bu = 0.f, bv = 0.f;
+    if (l < cnt) {
+        const uint32_t pair = rt_qpair[w * RT_QCAP + base + l];
+        uint32_t rank = pair >> 6;
+        owner = pair & 63u;
+        b = qb[owner];
+        if (b != 0) {
+            bt = b; brank = qk[owner];
+            const D3 rd = d3(qr[192 + owner], qr[256 + owner], qr[320 + owner]);
+            while (true) {
+                asm volatile("" ::: "memory");
+                const D3 ro = d3(qr[owner], qr[64 + owner], qr[128 + owner]);
+                const TriData T = tri_load(gptr(tris) + rank);
+                double t; float u, v;
+                vc.tris++; vc.units += 5;
+                if (tri_test_od(T, ro, rd, t, u, v)) {
+                    const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+                    if (tb < bt || (tb == bt && rank < brank)) { bt = tb; brank = rank; bu = u; bv = v; found = true; }
+                }
+                if (T.last) break;
+                ++rank;
+            }
+        }
+    }
+    if (__ballot(found)) {
+        if (found) atomicMin(&qb[owner], bt);
+        wave_lds_sync();
+        const bool cand = found && qb[owner] == bt;
+        if (cand && bt < b) qk[owner] = 0xFFFFFFFFu;   // a nearer distance than before the round: the old position is void
+        wave_lds_sync();
+        if (cand) atomicMin(&qk[owner], brank);
+        wave_lds_sync();
+        if (cand && qk[owner] == brank) rt_quv[w * 64 + owner] = make_float2(bu, bv);
+    }
+    wave_lds_sync();
+}
+
 // The thin ends of the walk.  Near the leaves the lanes of a packet have gone separate ways: half of a terrain's node
 // steps serve fewer than 16 of the 64 lanes, a quarter fewer than 4, and a step costs the wave the same whatever the
 // number.  So a child that few lanes entered is not walked by the packet: its (lane, node) pairs wait in a second
@@ -326,12 +413,17 @@ __device__ void test_pairs(const DTri* tris, uint32_t base, uint32_t cnt, Visits
 // the same values) -- and files the children entered as new pairs: leaves with the triangle pairs, inner nodes back
 // here.  The newest pairs go first (depth first), which keeps the queue short.
 // p = pairs to take (from the end of the queue); pn, qn = fill of the node and the triangle queue.
+// CLOSEST: a pair carries its node's entry distance and is dropped unread when the ray's best hit has come nearer
+// since; each lane files the children it entered farthest first, so that its nearest is the first to be taken.
+template <bool CLOSEST>
 __device__ void node_pairs(const DNode* nodes, float coord_max, uint32_t p, uint32_t& pn, uint32_t& qn, Visits& vc) {
     const uint32_t w = uni(threadIdx.x >> 6), l = lane_now();
     const uint32_t wq = w * RT_QCAP, wn = w * RT_NCAP;
     wave_lds_sync();
     pn -= p;
+    const float INF = asf(0x7F800000u);
     bool h0 = false, h1 = false, h2 = false, h3 = false;
+    float t0 = INF, t1 = INF, t2 = INF, t3 = INF;
     uint32_t owner = 0;
     rt_u4 ref; ref.x = ref.y = ref.z = ref.w = RT_NO_CHILD;
     vc.wnodes++;
@@ -339,18 +431,20 @@ __device__ void node_pairs(const DNode* nodes, float coord_max, uint32_t p, uint
         const uint32_t e = rt_qnode[wn + pn + l];
         owner = e & 63u;
         const unsigned long long b = rt_qbound[w * 64 + owner];
-        if (b != 0) {
+        const float limit = bound_limit<CLOSEST>(b);
+        bool go = b != 0;
+        if (CLOSEST) go = go && !(rt_qntn[wn + pn + l] > limit);
+        if (go) {
             const double* qr = rt_qray + w * 6 * 64 + owner;
             PRay pr;
             pray_axis_d(qr[0], qr[192], coord_max, pr.mx, pr.cminx, pr.cmaxx);
             pray_axis_d(qr[64], qr[256], coord_max, pr.my, pr.cminy, pr.cmaxy);
             pray_axis_d(qr[128], qr[320], coord_max, pr.mz, pr.cminz, pr.cmaxz);
-            const float limit = b > 1 ? limit_up(__longlong_as_double((long long)(b - 1ull))) : 0.f;
             const RT_GLOBAL rt_u4* rec = (const RT_GLOBAL rt_u4*)(gptr(nodes) + (e >> 6));
             UNode n;
             n.minx = rec[0]; n.miny = rec[1]; n.minz = rec[2]; n.maxx = rec[3]; n.maxy = rec[4]; n.maxz = rec[5]; ref = rec[6];
             vc.nodes++; vc.units += 7;
-            float t0, t1, t2, t3, f0, f1, f2, f3;
+            float f0, f1, f2, f3;
             RT_CHILD_PAIR(n, 0, t0, f0, t1, f1);
             RT_CHILD_PAIR(n, 2, t2, f2, t3, f3);
             h0 = fmaxf(t0, 0.f) <= fminf(f0, limit);
@@ -359,29 +453,49 @@ __device__ void node_pairs(const DNode* nodes, float coord_max, uint32_t p, uint
             h3 = fmaxf(t3, 0.f) <= fminf(f3, limit) && ref.w != RT_NO_CHILD;
         }
     }
-#define RT_PAIR_CHILD(h_, r_)                                                                              \
+#define RT_PAIR_CHILD(h_, r_, t_)                                                                          \
     {                                                                                                      \
         const unsigned long long mh_ = __ballot(h_), leaf_ = __ballot((int)(r_) < 0);                      \
         const unsigned long long ml_ = mh_ & leaf_, mi_ = mh_ & ~leaf_;                                    \
         if (in_mask(ml_)) rt_qpair[wq + qn + lanes_below(ml_)] = (((r_) & ~RT_LEAF_BIT) << 6) | owner;     \
         qn += (uint32_t)__popcll(ml_);                                                                     \
-        if (in_mask(mi_)) rt_qnode[wn + pn + lanes_below(mi_)] = ((r_) << 6) | owner;                      \
+        if (in_mask(mi_)) {                                                                                \
+            const uint32_t at_ = wn + pn + lanes_below(mi_);                                               \
+            rt_qnode[at_] = ((r_) << 6) | owner;                                                           \
+            if (CLOSEST) rt_qntn[at_] = (t_);                                                              \
+        }                                                                                                  \
         pn += (uint32_t)__popcll(mi_);                                                                     \
     }
-    RT_PAIR_CHILD(h3, ref.w)
-    RT_PAIR_CHILD(h2, ref.z)
-    RT_PAIR_CHILD(h1, ref.y)
-    RT_PAIR_CHILD(h0, ref.x)
+    if (CLOSEST) {
+        // this lane's children by entry distance (missed ones last), then four passes, farthest first
+        uint32_t r0 = ref.x, r1 = ref.y, r2 = ref.z, r3 = ref.w;
+        t0 = h0 ? t0 : INF; t1 = h1 ? t1 : INF; t2 = h2 ? t2 : INF; t3 = h3 ? t3 : INF;
+        RT_CSWAP(t0, r0, t1, r1); RT_CSWAP(t2, r2, t3, r3);
+        RT_CSWAP(t0, r0, t2, r2); RT_CSWAP(t1, r1, t3, r3);
+        RT_CSWAP(t1, r1, t2, r2);
+        RT_PAIR_CHILD(t3 < INF, r3, t3)
+        RT_PAIR_CHILD(t2 < INF, r2, t2)
+        RT_PAIR_CHILD(t1 < INF, r1, t1)
+        RT_PAIR_CHILD(t0 < INF, r0, t0)
+    } else {
+        RT_PAIR_CHILD(h3, ref.w, t3)
+        RT_PAIR_CHILD(h2, ref.z, t2)
+        RT_PAIR_CHILD(h1, ref.y, t1)
+        RT_PAIR_CHILD(h0, ref.x, t0)
+    }
 #undef RT_PAIR_CHILD
     wave_lds_sync();
 }
 
-// The shadow walk of one mesh for the parked rays.  Every lane of the wave must call it.  Lanes found blocked have
-// their bound word cleared.  With BUDGET the wave gives up after `budget` inner nodes and reports the lanes that
-// were still open in `unresolved` (their rays are then finished piecewise by other lanes, mesh_traverse_seg);
-// BUDGET = false compiles the step count out (large launches run without a budget).
-template <bool BUDGET>
-__device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, unsigned long long& unresolved) {
+// The walk of one mesh for the parked rays.  Every lane of the wave must call it.
+// CLOSEST = false, the shadow walk: lanes found blocked have their bound word cleared.  With BUDGET the wave gives
+// up after `budget` inner nodes and reports the lanes that were still open in `unresolved` (their rays are then
+// finished piecewise by other lanes, mesh_traverse_seg); BUDGET = false compiles the step count out (large launches
+// run without a budget).
+// CLOSEST = true: every ray's nearest hit (bound word, rt_qrank, rt_quv).  Nobody leaves the packet early, but the
+// distance limit of the box tests follows each ray's best hit, and children are taken nearest first.
+template <bool BUDGET, bool CLOSEST>
+__device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, unsigned long long& unresolved) {
     unresolved = 0;
     uint32_t steps = 0;
     // the mesh record is the same for the whole wave: read through the scalar cache, so that neither its address nor
@@ -409,8 +523,7 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
         pray_axis_d(qr_[0], qr_[192], B_, k.mx, lo_, hi_); k.enx = fminf(lo_, hi_); k.exx = fmaxf(lo_, hi_);
         pray_axis_d(qr_[64], qr_[256], B_, k.my, lo_, hi_); k.eny = fminf(lo_, hi_); k.exy = fmaxf(lo_, hi_);
         pray_axis_d(qr_[128], qr_[320], B_, k.mz, lo_, hi_); k.enz = fminf(lo_, hi_); k.exz = fmaxf(lo_, hi_);
-        // b - 1 = the bits of the bound, or 0 (a bound that cannot be met: the box distance limit 0 is as good as any)
-        k.limit = b_ > 1 ? limit_up(__longlong_as_double((long long)(b_ - 1ull))) : 0.f;
+        k.limit = bound_limit<CLOSEST>(b_);
         return k;
     };
     unsigned long long remaining;
@@ -436,14 +549,18 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
 
     // a child some lane entered: a leaf's (lane, leaf) pairs go on the triangle queue, an inner node on the stack,
     // or, entered by few lanes (and while there is room), on the node queue
-#define RT_CHILD_ENTERED(r_, m_)                                                                    \
+#define RT_CHILD_ENTERED(r_, m_, t_)                                                                \
     if (m_) {                                                                                       \
         const uint32_t c_ = (uint32_t)__popcll(m_);                                                 \
         if ((r_) & RT_LEAF_BIT) {                                                                   \
             if (in_mask(m_)) rt_qpair[wq + qn + lanes_below(m_)] = (((r_) & ~RT_LEAF_BIT) << 6) | lane_now(); \
             qn += c_;                                                                               \
         } else if (c_ <= RT_SPARSE && pn + c_ <= RT_NCAP) {                                         \
-            if (in_mask(m_)) rt_qnode[wn + pn + lanes_below(m_)] = ((r_) << 6) | lane_now();        \
+            if (in_mask(m_)) {                                                                      \
+                const uint32_t at_ = wn + pn + lanes_below(m_);                                     \
+                rt_qnode[at_] = ((r_) << 6) | lane_now();                                           \
+                if (CLOSEST) rt_qntn[at_] = (t_);                                                   \
+            }                                                                                       \
             pn += c_;                                                                               \
         } else st.push((r_), (m_));                                                                 \
     }
@@ -485,9 +602,12 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
                 // code once): when 48 pairs wait, or nothing else is left to do
                 const uint32_t cnt = qn < 64 ? qn : 64;
                 qn -= cnt;
-                test_pairs(tris, qn, cnt, vc);
-                alive &= ~__ballot(parked_blocked());
-                if (!alive) break;
+                if (CLOSEST) test_pairs_closest(tris, qn, cnt, vc);
+                else {
+                    test_pairs(tris, qn, cnt, vc);
+                    alive &= ~__ballot(parked_blocked());
+                    if (!alive) break;
+                }
                 continue;
             }
             if (pn >= RT_NFLUSH || (pn > 0 && st.sp == 0)) {
@@ -503,7 +623,7 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
                     --pn;
                     st.push(e >> 6, 1ull << (e & 63u));
                 } else {
-                    node_pairs(nodes, Mg.coord_max, p, pn, qn, vc);
+                    node_pairs<CLOSEST>(nodes, Mg.coord_max, p, pn, qn, vc);
                     continue;
                 }
             }
@@ -531,10 +651,27 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
                     unsigned long long m2 = box_lanes(t2, f2, K.limit) & inmask, m3 = box_lanes(t3, f3, K.limit) & inmask;
                     if (ref[2] == RT_NO_CHILD) m2 = 0;
                     if (ref[3] == RT_NO_CHILD) m3 = 0;
-                    RT_CHILD_ENTERED(ref[3], m3)
-                    RT_CHILD_ENTERED(ref[2], m2)
-                    RT_CHILD_ENTERED(ref[1], m1)
-                    RT_CHILD_ENTERED(ref[0], m0)   // pushed last: walked first (the order makes no measurable difference)
+                    if (CLOSEST) {
+                        // nearest first, by the entry distance of the first lane in each child (rays of a packet
+                        // agree mostly); children nobody entered sort last
+                        const float INF = asf(0x7F800000u);
+                        unsigned long long s0 = m0, s1 = m1, s2 = m2, s3 = m3;
+                        uint32_t r0 = ref[0], r1 = ref[1], r2 = ref[2], r3 = ref[3];
+                        float k0 = s0 ? first_lane_f(t0, s0) : INF, k1 = s1 ? first_lane_f(t1, s1) : INF;
+                        float k2 = s2 ? first_lane_f(t2, s2) : INF, k3 = s3 ? first_lane_f(t3, s3) : INF;
+                        RT_UCSWAP_T(k0, r0, s0, t0, k1, r1, s1, t1); RT_UCSWAP_T(k2, r2, s2, t2, k3, r3, s3, t3);
+                        RT_UCSWAP_T(k0, r0, s0, t0, k2, r2, s2, t2); RT_UCSWAP_T(k1, r1, s1, t1, k3, r3, s3, t3);
+                        RT_UCSWAP_T(k1, r1, s1, t1, k2, r2, s2, t2);
+                        RT_CHILD_ENTERED(r3, s3, t3)
+                        RT_CHILD_ENTERED(r2, s2, t2)
+                        RT_CHILD_ENTERED(r1, s1, t1)
+                        RT_CHILD_ENTERED(r0, s0, t0)
+                    } else {
+                        RT_CHILD_ENTERED(ref[3], m3, t3)
+                        RT_CHILD_ENTERED(ref[2], m2, t2)
+                        RT_CHILD_ENTERED(ref[1], m1, t1)
+                        RT_CHILD_ENTERED(ref[0], m0, t0)   // pushed last: walked first (the order makes no measurable difference)
+                    }
                 } while (st.sp > 0 && qn < RT_QFLUSH && pn < RT_NFLUSH);
             }
         }
@@ -543,12 +680,34 @@ __device__ void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget
 #undef RT_PAIR_ENTRY_EXIT
 #undef RT_CHILD_ENTERED
 }
+template <bool BUDGET>
+DEV void packet_any_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, unsigned long long& unresolved) {
+    packet_deferred<BUDGET, false>(Mp, vc, budget, unresolved);
+}
+// Closest hit of the wave's rays in one mesh, nearer than `bound` (ties to the lower leaf-order position): the walk
+// above with the rays parked for it.  Every lane of the wave must call it.
+__device__ bool packet_closest_deferred(const DMesh* Mp, const Ray& ray, bool active, double bound, MeshHit& mh, Visits& vc) {
+    park_rays_closest(ray, active, bound);
+    unsigned long long unresolved;
+    packet_deferred<false, true>(Mp, vc, 0, unresolved);
+    wave_lds_sync();
+    const uint32_t at = uni(threadIdx.x >> 6) * 64 + lane_now();
+    const unsigned long long b = rt_qbound[at];
+    mh.n = 0; mh.t0 = bound; mh.t1 = bound; mh.r0 = 0; mh.u = 0.f; mh.v = 0.f;
+    if (active && b != 0 && b < (unsigned long long)__double_as_longlong(bound)) {
+        mh.n = 1; mh.t0 = __longlong_as_double((long long)b); mh.t1 = mh.t0; mh.r0 = rt_qrank[at];
+        const float2 uv = rt_quv[at]; mh.u = uv.x; mh.v = uv.y;
+    }
+    return mh.n > 0;
+}
 
 // Scene::cast_ray_once for a whole wave (scene.rs:57-82): the object loop is uniform, meshes are walked as a
 // packet.  Every lane calls it; `active` lanes carry a ray.
 // FAR = false: the scene has no mesh whose material needs Hit::far, and the lane-by-lane two-hit walk is left out
 // of the kernel (it costs registers, hence waves per SIMD, even when it never runs).
-template <bool FAR>
+// DEFER: the meshes are walked by packet_closest_deferred (triangle tests and thin ends of the walk set aside)
+// instead of packet_traverse.
+template <bool FAR, bool DEFER = false>
 __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active, Closest& c, Visits& vc) {
     c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
     bool any = false;
@@ -564,7 +723,8 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
                 if (active && mesh_traverse<TRAV_TWO>(S.meshes[payload], ray, INFINITY, mh, vc) && (!any || mh.t0 < c.t)) {
                     c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.n >= 2 ? mh.t1 : mh.t0; c.u = mh.u; c.v = mh.v; any = true;
                 }
-            } else if (packet_traverse(S.meshes[payload], ray, active, any ? c.t : INFINITY, mh, vc)) {
+            } else if (DEFER ? packet_closest_deferred(S.meshes + payload, ray, active, any ? c.t : INFINITY, mh, vc)
+                             : packet_traverse(S.meshes[payload], ray, active, any ? c.t : INFINITY, mh, vc)) {
                 c.obj = oi; c.rank = mh.r0; c.t = mh.t0; c.t2 = mh.t0; c.u = mh.u; c.v = mh.v; any = true;
             }
             continue;

@@ -208,7 +208,7 @@ DEV void load_hit(const DLevel& L, uint32_t i, const Ray& ray, Hit& h) {
 #define RT_TRACE_PACKET_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
 #endif
 // MESHES = false: a scene of analytic objects only (lane by lane, no budget): the mesh walks stay out of the kernel.
-template <bool COUNT, bool PACKET, bool BUDGET, bool FAR, bool MESHES>
+template <bool COUNT, bool PACKET, bool BUDGET, bool FAR, bool MESHES, bool DEFER = false>
 DEV void trace_body(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, uint32_t* hitlist, double* hs, uint32_t stride,
                     DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -223,7 +223,7 @@ DEV void trace_body(const DScene* Sp, DLevel L, uint32_t n, const unsigned long 
     bool hit = false;
     if (PACKET) {
         // the wave's rays are coherent (primary rays of an 8x8 pixel block) and walk the BVH together
-        hit = cast_closest_packet<FAR>(S, ray, active, c, vc);
+        hit = cast_closest_packet<FAR, DEFER>(S, ray, active, c, vc);
     } else if (active && !BUDGET) {
         hit = MESHES ? cast_closest<FAR>(S, ray, c, vc) : cast_closest_analytic(S, ray, c);
     } else if (active) {
@@ -249,10 +249,10 @@ __global__ __launch_bounds__(RT_BLOCK) RT_TRACE_ATTR void k_trace(const DScene* 
     static_assert(!PACKET, "the packet variants are k_trace_packet");
     trace_body<COUNT, false, BUDGET, FAR, MESHES>(Sp, L, n, n_dev, hitlist, hs, stride, C, LC, longlist, lp);
 }
-template <bool COUNT, bool FAR>
+template <bool COUNT, bool FAR, bool DEFER = false>
 __global__ __launch_bounds__(RT_BLOCK) RT_TRACE_PACKET_ATTR void k_trace_packet(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, uint32_t* hitlist, double* hs, uint32_t stride,
                                                     DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
-    trace_body<COUNT, true, false, FAR, true>(Sp, L, n, n_dev, hitlist, hs, stride, C, LC, longlist, lp);
+    trace_body<COUNT, true, false, FAR, true, DEFER>(Sp, L, n, n_dev, hitlist, hs, stride, C, LC, longlist, lp);
 }
 
 // The listed long rays of a level, RT_SEGS lanes each: lane k walks piece k of the ray through every mesh, the

@@ -118,6 +118,8 @@ struct rt_ctx {
     bool any_need_far = false;                        // some mesh's material needs Hit::far (transparency with ior == 1)
     bool any_mesh_refracts = false;                   // some mesh has a refracting material (transparency with ior != 1): k_spawn needs the mesh walk
     uint32_t packet_depth = 0;                        // levels 0..packet_depth trace their rays as wave packets
+    bool defer_small = true;                          // ... also in launches small enough for the long-ray budgets
+    uint32_t defer_from = 1;                          // levels from this one on walk meshes as packets with the triangle tests and the thin ends set aside (scenes without need_far meshes)
     bool serial = false;                              // RTGPU_SERIAL=1: everything on the main stream (profiling: kernels do not overlap)
     uint32_t long_below = 300000u;                  // ... applied to launches of fewer rays than this
     int count_visits = 0;                             // RTGPU_COUNT_VISITS: bit 0 k_trace, bit 1 k_shadow, bit 2 k_shade instrumented
@@ -740,12 +742,15 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
         HIP_TRY(c, hipEventRecord(W.ev[LW_T0], s));
         // depth 0 of a scene with meshes: primary rays, 8x8 pixel blocks per wave -> coherent packets; deeper rays
         // (and scenes of analytic objects only, whose object tree is walked per lane anyway) lane by lane
+        const bool deferred = c->hscene.n_meshes != 0 && !c->any_need_far && depth >= c->defer_from && (!lp.budget_lane || c->defer_small);
+        if (deferred) lp.budget_lane = 0;
         {
             auto launch = [&](auto kern) {
                 hipLaunchKernelGGL(kern, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, n_dev, hitlist, hs, n, dc, lc, long_trace, lp);
             };
             const bool cnt = (c->count_visits & 1) != 0;
             if (c->hscene.n_meshes == 0) { if (cnt) launch(k_trace<true, false, false, false, false>); else launch(k_trace<false, false, false, false, false>); }
+            else if (deferred) { if (cnt) launch(k_trace_packet<true, false, true>); else launch(k_trace_packet<false, false, true>); }
             else if (depth <= c->packet_depth) {   // (packets pay for mesh walks only)
                 if (c->any_need_far) { if (cnt) launch(k_trace_packet<true, true>); else launch(k_trace_packet<false, true>); }
                 else { if (cnt) launch(k_trace_packet<true, false>); else launch(k_trace_packet<false, false>); }
@@ -940,6 +945,8 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         c->serial = std::getenv("RTGPU_SERIAL") != nullptr;
         if (const char* b = std::getenv("RTGPU_SYNC_LEVELS")) c->sync_levels = std::strtol(b, nullptr, 10) != 0;
         if (const char* b = std::getenv("RTGPU_PACKET_DEPTH")) c->packet_depth = (uint32_t)std::strtoul(b, nullptr, 10);
+        if (const char* b = std::getenv("RTGPU_DEFER_FROM")) c->defer_from = (uint32_t)std::strtoul(b, nullptr, 10);
+        if (const char* b = std::getenv("RTGPU_DEFER_SMALL")) c->defer_small = b[0] != '0';
         if (const char* b = std::getenv("RTGPU_BUDGET_BELOW")) c->long_below = (uint32_t)std::strtoul(b, nullptr, 10);
     }
     for (auto& ev : c->ev) ev = nullptr;

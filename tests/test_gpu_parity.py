@@ -345,17 +345,22 @@ def test_full_size_config4_sampled_and_properties(gpu_ctx):
     (scenes.terrain_scene, (256, 144, 24, 24)),
     (scenes.small_mixed_scene, (128, 96)),
 ])
-def test_long_ray_lists_keep_parity(builder, args, monkeypatch):
-    """walk budgets of a few nodes put most rays on the long-ray lists (16 pieces per ray, merged): same frame"""
+@pytest.mark.parametrize("lane_by_lane", [True, False])
+def test_long_ray_lists_keep_parity(builder, args, lane_by_lane, monkeypatch):
+    """walk budgets of a few nodes put most rays on the long-ray lists (16 pieces per ray, merged): same frame.
+    lane_by_lane: levels >= 1 are traced lane by lane (the walks that have a budget) instead of as packets with the
+    triangle tests set aside (which have none: only the shadow casts fill a list then)."""
     monkeypatch.setenv("RTGPU_BUDGET_LANE", "3")
     monkeypatch.setenv("RTGPU_BUDGET_WAVE", "4")
     monkeypatch.setenv("RTGPU_BUDGET_BELOW", "4000000000")
+    if lane_by_lane:
+        monkeypatch.setenv("RTGPU_DEFER_FROM", "99")
     s = builder(*args)
     with ra.Context(0) as ctx:
         ctx.upload(s)
         rgb, ids, st = ctx.render(ids=True)
     o_rgb, o_ids, o_st, oc = oracle.render(s, 0)
-    assert st.long_trace > 0 and st.long_shadow > 0
+    assert st.long_shadow > 0 and (st.long_trace > 0) == lane_by_lane
     assert_parity(rgb, ids, o_rgb, o_ids, exact_floor=1.0)
     assert ray_counts(st) == ray_counts(o_st)
 
@@ -402,6 +407,31 @@ def test_random_scenes_with_long_ray_lists(monkeypatch):
         for seed in [12151] + list(range(12000, 12040)):
             s, _ = fz.random_scene(seed)
             _assert_identical(ctx, s)
+
+
+@pytest.mark.parametrize("env", [
+    {"RTGPU_DEFER_FROM": "0"},                                  # every level: packets, triangle tests and thin ends set aside
+    {"RTGPU_DEFER_FROM": "99"},                                 # level 0 as plain packets, deeper levels lane by lane
+    {"RTGPU_DEFER_FROM": "99", "RTGPU_PACKET_DEPTH": "8"},      # every level as plain packets
+], ids=["deferred-from-0", "lane-by-lane", "plain-packets"])
+def test_every_way_of_tracing_a_level_gives_the_same_frame(env, monkeypatch):
+    """The closest casts of a level run as plain packets, as packets whose triangle tests and thinly populated nodes
+    wait in queues, or lane by lane (the default mixes them by level): random scenes equal the oracle byte for byte
+    under each, and so do the icospheres of the reference's README, whose rays through shared edges and vertices hit
+    two or more triangles at exactly the same distance (the lower position in the tree's leaf order must win)."""
+    from raytracer_amd.scene import read_png
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    fz = _fuzz_module()
+    with ra.Context(0) as ctx:
+        for seed in range(2000, 2030):
+            s, _ = fz.random_scene(seed)
+            _assert_identical(ctx, s)
+        for builder, args in ((scenes.synthetic_terrain_scene, (256, 144, 48)), (scenes.terrain_scene, (256, 144, 24, 24))):
+            _assert_identical(ctx, builder(*args))
+        for k, order in ((1, 0), (2, 2), (3, 5)):
+            ctx.upload(scenes.icosphere_scene(order))
+            assert np.array_equal(ctx.render()[0], read_png(os.path.join(GOLDEN, f"readme_11_22_2021_{k}.png"))), order
 
 
 def test_sdl_script_renders_like_the_oracle(gpu_ctx):
