@@ -241,6 +241,9 @@ __shared__ uint32_t rt_qpair[RT_PWAVES * RT_QCAP];
 #ifndef RT_SPARSE
 #define RT_SPARSE 16    /* a child entered by at most this many lanes leaves the packet walk */
 #endif
+#ifndef RT_SPARSE_CLOSEST
+#define RT_SPARSE_CLOSEST RT_SPARSE   /* the same for a closest-hit walk */
+#endif
 #ifndef RT_NCAP
 #define RT_NCAP 224
 #endif
@@ -248,6 +251,9 @@ __shared__ uint32_t rt_qpair[RT_PWAVES * RT_QCAP];
 #define RT_NFLUSH 48    /* node pairs waiting at which the packet walk stops for a round of node tests */
 #endif
 __shared__ uint32_t rt_qnode[RT_PWAVES * RT_NCAP];
+// how much of the node queue a walk uses (<= RT_NCAP; rt_context_create lowers it on request, so that tests can make
+// the queue overflow at will)
+__device__ uint32_t rt_node_cap = RT_NCAP;
 // closest-hit walks only: the entry distance of each queued node pair (a pair whose node lies beyond the ray's best
 // hit by the time its turn comes is dropped unread), and per ray the best hit's triangle and barycentrics
 __shared__ float rt_qntn[RT_PWAVES * RT_NCAP];
@@ -505,6 +511,7 @@ __device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, un
     const DTri* tris = Mg.tris;
     const uint32_t w = uni(threadIdx.x >> 6);
     const uint32_t wq = w * RT_QCAP, wn = w * RT_NCAP;
+    const uint32_t ncap = uni(rt_node_cap) < RT_NCAP ? uni(rt_node_cap) : RT_NCAP;
     // Per-lane constants of the box test, as in PRay but filed by role: c_entry goes with the plane the ray meets
     // first along the axis, c_exit with the other.  Which plane that is (min or max) depends on the direction's sign
     // only, and the walk below handles lanes of one sign pattern at a time, so it is settled per walk, not per test.
@@ -555,7 +562,7 @@ __device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, un
         if ((r_) & RT_LEAF_BIT) {                                                                   \
             if (in_mask(m_)) rt_qpair[wq + qn + lanes_below(m_)] = (((r_) & ~RT_LEAF_BIT) << 6) | lane_now(); \
             qn += c_;                                                                               \
-        } else if (c_ <= RT_SPARSE && pn + c_ <= RT_NCAP) {                                         \
+        } else if (c_ <= (CLOSEST ? RT_SPARSE_CLOSEST : RT_SPARSE) && pn + c_ <= ncap) {            \
             if (in_mask(m_)) {                                                                      \
                 const uint32_t at_ = wn + pn + lanes_below(m_);                                     \
                 rt_qnode[at_] = ((r_) << 6) | lane_now();                                           \
@@ -616,7 +623,7 @@ __device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, un
                 // its newest pair back to the packet walk (whose stack is bounded by the tree's depth).
                 if (BUDGET && ++steps > budget) { unresolved = 1; break; }
                 uint32_t p = pn < 64 ? pn : 64;
-                const uint32_t room = (RT_NCAP - pn) / 3;
+                const uint32_t room = (ncap - pn) / 3;
                 if (room < p) p = room;
                 if (p == 0) {
                     const uint32_t e = uni(rt_qnode[wn + pn - 1]);

@@ -249,10 +249,19 @@ __global__ __launch_bounds__(RT_BLOCK) RT_TRACE_ATTR void k_trace(const DScene* 
     static_assert(!PACKET, "the packet variants are k_trace_packet");
     trace_body<COUNT, false, BUDGET, FAR, MESHES>(Sp, L, n, n_dev, hitlist, hs, stride, C, LC, longlist, lp);
 }
-template <bool COUNT, bool FAR, bool DEFER = false>
+template <bool COUNT, bool FAR>
 __global__ __launch_bounds__(RT_BLOCK) RT_TRACE_PACKET_ATTR void k_trace_packet(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, uint32_t* hitlist, double* hs, uint32_t stride,
                                                     DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
-    trace_body<COUNT, true, false, FAR, true, DEFER>(Sp, L, n, n_dev, hitlist, hs, stride, C, LC, longlist, lp);
+    trace_body<COUNT, true, false, FAR, true, false>(Sp, L, n, n_dev, hitlist, hs, stride, C, LC, longlist, lp);
+}
+// packets whose triangle tests and thinly populated nodes wait in queues (scenes without need_far meshes)
+#ifndef RT_TRACE_DEFER_ATTR
+#define RT_TRACE_DEFER_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) RT_TRACE_DEFER_ATTR void k_trace_deferred(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, uint32_t* hitlist, double* hs, uint32_t stride,
+                                                    DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
+    trace_body<COUNT, true, false, false, true, true>(Sp, L, n, n_dev, hitlist, hs, stride, C, LC, longlist, lp);
 }
 
 // The listed long rays of a level, RT_SEGS lanes each: lane k walks piece k of the ray through every mesh, the

@@ -750,7 +750,7 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
             };
             const bool cnt = (c->count_visits & 1) != 0;
             if (c->hscene.n_meshes == 0) { if (cnt) launch(k_trace<true, false, false, false, false>); else launch(k_trace<false, false, false, false, false>); }
-            else if (deferred) { if (cnt) launch(k_trace_packet<true, false, true>); else launch(k_trace_packet<false, false, true>); }
+            else if (deferred) { if (cnt) launch(k_trace_deferred<true>); else launch(k_trace_deferred<false>); }
             else if (depth <= c->packet_depth) {   // (packets pay for mesh walks only)
                 if (c->any_need_far) { if (cnt) launch(k_trace_packet<true, true>); else launch(k_trace_packet<false, true>); }
                 else { if (cnt) launch(k_trace_packet<true, false>); else launch(k_trace_packet<false, false>); }
@@ -953,6 +953,14 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     auto bail = [&](const char* what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); rt_ctx_destroy(c); return RT_ERR_DEVICE; };
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = scratch_address(device_id, &c->scratch)) != hipSuccess) return bail("hipGetSymbolAddress", e);
+    {
+        // entries of the packets' node queue in use: all of them, unless a test asks for fewer to make it overflow
+        // (a variable of the device, so the last context created on a device decides)
+        uint32_t v = RT_NCAP;
+        if (const char* b = std::getenv("RTGPU_NODE_QUEUE")) v = (uint32_t)std::strtoul(b, nullptr, 10);
+        v = v < 4u ? 4u : (v > (uint32_t)RT_NCAP ? (uint32_t)RT_NCAP : v);
+        if ((e = hipMemcpyToSymbol(HIP_SYMBOL(rt_node_cap), &v, sizeof(v))) != hipSuccess) return bail("hipMemcpyToSymbol", e);
+    }
     // (all streams at the default priority: mixed priorities hung the frame on this ROCm)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     // Queued all at once (no level sizes read back), a frame's five shadow chains wait in the hardware queues for events

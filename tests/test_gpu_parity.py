@@ -413,7 +413,8 @@ def test_random_scenes_with_long_ray_lists(monkeypatch):
     {"RTGPU_DEFER_FROM": "0"},                                  # every level: packets, triangle tests and thin ends set aside
     {"RTGPU_DEFER_FROM": "99"},                                 # level 0 as plain packets, deeper levels lane by lane
     {"RTGPU_DEFER_FROM": "99", "RTGPU_PACKET_DEPTH": "8"},      # every level as plain packets
-], ids=["deferred-from-0", "lane-by-lane", "plain-packets"])
+    {"RTGPU_DEFER_FROM": "0", "RTGPU_NODE_QUEUE": "12"},        # ... with a node queue so short that it keeps overflowing
+], ids=["deferred-from-0", "lane-by-lane", "plain-packets", "short-node-queue"])
 def test_every_way_of_tracing_a_level_gives_the_same_frame(env, monkeypatch):
     """The closest casts of a level run as plain packets, as packets whose triangle tests and thinly populated nodes
     wait in queues, or lane by lane (the default mixes them by level): random scenes equal the oracle byte for byte
