@@ -104,7 +104,10 @@ DEV PRay pray_new(const Ray& r, float B) {
 // lanes (of the whole wave) whose ray meets the box before `limit`: entry <= exit, exit >= 0, entry <= limit.
 // Every value is finite (finite boxes, clamped 1/direction), so the ordered compare needs no NaN case.
 #define RT_FCMP_OLE 5
+// SIGNED: distances of either sign count (entry <= exit, exit >= 0, entry <= limit, nothing clamped at the origin).
+template <bool SIGNED = false>
 DEV unsigned long long box_lanes(float tn, float tf, float limit) {
+    if (SIGNED) return __builtin_amdgcn_fcmpf(tn, fminf(tf, limit), RT_FCMP_OLE) & __builtin_amdgcn_fcmpf(0.f, tf, RT_FCMP_OLE);
     return __builtin_amdgcn_fcmpf(fmaxf(tn, 0.f), fminf(tf, limit), RT_FCMP_OLE);
 }
 
@@ -319,6 +322,27 @@ DEV void park_rays_closest(const Ray& ray, bool active, double bound) {
     rt_qrank[w * 64 + l] = 0;
     wave_lds_sync();
 }
+// A distance of either sign as an unsigned word in the same order (the walk of an object tree: a ray that starts
+// inside a sphere meets it at a negative distance, sphere.rs:33-62); never 0 for a number.
+DEV unsigned long long dkey(double t) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(t);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+DEV double dkey_inv(unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+}
+// Parks the rays for a closest-hit walk of the object tree: the bound word is dkey(best distance so far), 0 = no ray;
+// `rank` is the object that holds that distance (a later object must be nearer, or as near with a lower index,
+// scene.rs:57-82).
+DEV void park_rays_objects(const Ray& ray, bool active, double bound, uint32_t rank) {
+    const uint32_t w = uni(threadIdx.x >> 6), l = lane_now();
+    double* qr = rt_qray + w * 6 * 64;
+    qr[l] = ray.o.x; qr[64 + l] = ray.o.y; qr[128 + l] = ray.o.z;
+    qr[192 + l] = ray.d.x; qr[256 + l] = ray.d.y; qr[320 + l] = ray.d.z;
+    rt_qbound[w * 64 + l] = active ? dkey(bound) : 0ull;
+    rt_qrank[w * 64 + l] = rank;
+    wave_lds_sync();
+}
 DEV bool parked_blocked() { return rt_qbound[uni(threadIdx.x >> 6) * 64 + lane_now()] == 0; }   // (one word per thread of the block)
 
 // One batch: lane k takes pair base + k (k < cnt).
@@ -353,8 +377,9 @@ __device__ void test_pairs(const DTri* tris, uint32_t base, uint32_t cnt, Visits
 }
 
 // the f32 distance limit of a bound word (never below the bound itself)
-template <bool CLOSEST>
+template <bool CLOSEST, bool OBJ = false>
 DEV float bound_limit(unsigned long long b) {
+    if (CLOSEST && OBJ) return limit_up(dkey_inv(b));
     if (CLOSEST) return limit_up(__longlong_as_double((long long)b));
     // b - 1 = the bits of the bound, or 0 (a bound that cannot be met: the box distance limit 0 is as good as any)
     return b > 1 ? limit_up(__longlong_as_double((long long)(b - 1ull))) : 0.f;
@@ -411,6 +436,52 @@ __device__ void test_pairs_closest(const DTri* tris, uint32_t base, uint32_t cnt
     wave_lds_sync();
 }
 
+// One batch of the walk of an object tree: lane k takes pair base + k = (object, ray) and runs the object's own test
+// (sphere.rs:33-62, aabb.rs:18-67).  Shadow walk: a hit no farther than the bound clears the owner's bound word.
+// Closest walk: as test_pairs_closest, with the object's index in the place of the triangle's position.
+template <bool CLOSEST>
+__device__ void test_pairs_obj(const DScene& S, uint32_t base, uint32_t cnt, Visits& vc) {
+    const uint32_t w = uni(threadIdx.x >> 6), l = lane_now();
+    const double* qr = rt_qray + w * 6 * 64;
+    unsigned long long* qb = rt_qbound + w * 64;
+    uint32_t* qk = rt_qrank + w * 64;
+    wave_lds_sync();
+    vc.wtris++;
+    bool found = false;
+    uint32_t owner = 0, oi = 0;
+    unsigned long long b = 0, key = 0;
+    if (l < cnt) {
+        const uint32_t pair = rt_qpair[w * RT_QCAP + base + l];
+        oi = pair >> 6;
+        owner = pair & 63u;
+        b = qb[owner];
+        if (b != 0) {
+            Ray r;
+            r.o = d3(qr[owner], qr[64 + owner], qr[128 + owner]);
+            r.d = d3(qr[192 + owner], qr[256 + owner], qr[320 + owner]);
+            const RT_GLOBAL DObject* op = gptr(S.objects) + oi;
+            const uint32_t kind = op->kind, payload = op->payload;
+            double near; bool hit;
+            vc.tris++; vc.units += 3;
+            if (kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)payload, r, near);
+            else { r.m = d3(1. / r.d.x, 1. / r.d.y, 1. / r.d.z); hit = box_near(gptr(S.boxes) + 6 * (size_t)payload, r, near); }
+            if (hit) {
+                if (!CLOSEST) { if (b > 1 && near <= __longlong_as_double((long long)(b - 1ull))) qb[owner] = 0; }
+                else { key = dkey(near); found = key < b || (key == b && oi < qk[owner]); }
+            }
+        }
+    }
+    if (CLOSEST && __ballot(found)) {
+        if (found) atomicMin(&qb[owner], key);
+        wave_lds_sync();
+        const bool cand = found && qb[owner] == key;
+        if (cand && key < b) qk[owner] = 0xFFFFFFFFu;
+        wave_lds_sync();
+        if (cand) atomicMin(&qk[owner], oi);
+    }
+    wave_lds_sync();
+}
+
 // The thin ends of the walk.  Near the leaves the lanes of a packet have gone separate ways: half of a terrain's node
 // steps serve fewer than 16 of the 64 lanes, a quarter fewer than 4, and a step costs the wave the same whatever the
 // number.  So a child that few lanes entered is not walked by the packet: its (lane, node) pairs wait in a second
@@ -421,7 +492,8 @@ __device__ void test_pairs_closest(const DTri* tris, uint32_t base, uint32_t cnt
 // p = pairs to take (from the end of the queue); pn, qn = fill of the node and the triangle queue.
 // CLOSEST: a pair carries its node's entry distance and is dropped unread when the ray's best hit has come nearer
 // since; each lane files the children it entered farthest first, so that its nearest is the first to be taken.
-template <bool CLOSEST>
+// OBJ: the tree is a scene's object tree (distances of either sign: nothing is clamped at the ray's origin).
+template <bool CLOSEST, bool OBJ>
 __device__ void node_pairs(const DNode* nodes, float coord_max, uint32_t p, uint32_t& pn, uint32_t& qn, Visits& vc) {
     const uint32_t w = uni(threadIdx.x >> 6), l = lane_now();
     const uint32_t wq = w * RT_QCAP, wn = w * RT_NCAP;
@@ -437,7 +509,7 @@ __device__ void node_pairs(const DNode* nodes, float coord_max, uint32_t p, uint
         const uint32_t e = rt_qnode[wn + pn + l];
         owner = e & 63u;
         const unsigned long long b = rt_qbound[w * 64 + owner];
-        const float limit = bound_limit<CLOSEST>(b);
+        const float limit = bound_limit<CLOSEST, OBJ>(b);
         bool go = b != 0;
         if (CLOSEST) go = go && !(rt_qntn[wn + pn + l] > limit);
         if (go) {
@@ -453,10 +525,17 @@ __device__ void node_pairs(const DNode* nodes, float coord_max, uint32_t p, uint
             float f0, f1, f2, f3;
             RT_CHILD_PAIR(n, 0, t0, f0, t1, f1);
             RT_CHILD_PAIR(n, 2, t2, f2, t3, f3);
-            h0 = fmaxf(t0, 0.f) <= fminf(f0, limit);
-            h1 = fmaxf(t1, 0.f) <= fminf(f1, limit);
-            h2 = fmaxf(t2, 0.f) <= fminf(f2, limit) && ref.z != RT_NO_CHILD;
-            h3 = fmaxf(t3, 0.f) <= fminf(f3, limit) && ref.w != RT_NO_CHILD;
+            if (CLOSEST && OBJ) {
+                h0 = t0 <= fminf(f0, limit) && f0 >= 0.f;
+                h1 = t1 <= fminf(f1, limit) && f1 >= 0.f;
+                h2 = t2 <= fminf(f2, limit) && f2 >= 0.f && ref.z != RT_NO_CHILD;
+                h3 = t3 <= fminf(f3, limit) && f3 >= 0.f && ref.w != RT_NO_CHILD;
+            } else {
+                h0 = fmaxf(t0, 0.f) <= fminf(f0, limit);
+                h1 = fmaxf(t1, 0.f) <= fminf(f1, limit);
+                h2 = fmaxf(t2, 0.f) <= fminf(f2, limit) && ref.z != RT_NO_CHILD;
+                h3 = fmaxf(t3, 0.f) <= fminf(f3, limit) && ref.w != RT_NO_CHILD;
+            }
         }
     }
 #define RT_PAIR_CHILD(h_, r_, t_)                                                                          \
@@ -500,8 +579,10 @@ __device__ void node_pairs(const DNode* nodes, float coord_max, uint32_t p, uint
 // run without a budget).
 // CLOSEST = true: every ray's nearest hit (bound word, rt_qrank, rt_quv).  Nobody leaves the packet early, but the
 // distance limit of the box tests follows each ray's best hit, and children are taken nearest first.
-template <bool BUDGET, bool CLOSEST>
-__device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, unsigned long long& unresolved) {
+// OBJ: Mp describes the scene's object tree (DScene::tlas_mesh: same records, a leaf child is an object), `Sp` is the
+// scene; the parked rays are those whose direction is of unit length (the others do not cull, tlas_culls).
+template <bool BUDGET, bool CLOSEST, bool OBJ = false>
+__device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, unsigned long long& unresolved, const DScene* Sp = nullptr) {
     unresolved = 0;
     uint32_t steps = 0;
     // the mesh record is the same for the whole wave: read through the scalar cache, so that neither its address nor
@@ -530,7 +611,7 @@ __device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, un
         pray_axis_d(qr_[0], qr_[192], B_, k.mx, lo_, hi_); k.enx = fminf(lo_, hi_); k.exx = fmaxf(lo_, hi_);
         pray_axis_d(qr_[64], qr_[256], B_, k.my, lo_, hi_); k.eny = fminf(lo_, hi_); k.exy = fmaxf(lo_, hi_);
         pray_axis_d(qr_[128], qr_[320], B_, k.mz, lo_, hi_); k.enz = fminf(lo_, hi_); k.exz = fmaxf(lo_, hi_);
-        k.limit = bound_limit<CLOSEST>(b_);
+        k.limit = bound_limit<CLOSEST, OBJ>(b_);
         return k;
     };
     unsigned long long remaining;
@@ -545,7 +626,8 @@ __device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, un
         const float ay = fmaf(ny ? hi[1] : lo[1], k.my, k.eny), by = fmaf(ny ? lo[1] : hi[1], k.my, k.exy);
         const float az = fmaf(nz ? hi[2] : lo[2], k.mz, k.enz), bz = fmaf(nz ? lo[2] : hi[2], k.mz, k.exz);
         const float tn = fmaxf(fmaxf(ax, ay), az), tf = fminf(fminf(bx, by), bz);
-        const bool root_hit = rt_qbound[w * 64 + lane_now()] != 0 && fmaxf(tn, 0.f) <= fminf(tf, k.limit);
+        const bool root_hit = rt_qbound[w * 64 + lane_now()] != 0 &&
+                              (CLOSEST && OBJ ? tn <= fminf(tf, k.limit) && tf >= 0.f : fmaxf(tn, 0.f) <= fminf(tf, k.limit));
         remaining = __ballot(root_hit);
     }
     if (!remaining) return;
@@ -609,9 +691,10 @@ __device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, un
                 // code once): when 48 pairs wait, or nothing else is left to do
                 const uint32_t cnt = qn < 64 ? qn : 64;
                 qn -= cnt;
-                if (CLOSEST) test_pairs_closest(tris, qn, cnt, vc);
-                else {
-                    test_pairs(tris, qn, cnt, vc);
+                if (OBJ) test_pairs_obj<CLOSEST>(*Sp, qn, cnt, vc);
+                else if (CLOSEST) test_pairs_closest(tris, qn, cnt, vc);
+                else test_pairs(tris, qn, cnt, vc);
+                if (!CLOSEST) {
                     alive &= ~__ballot(parked_blocked());
                     if (!alive) break;
                 }
@@ -630,7 +713,7 @@ __device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, un
                     --pn;
                     st.push(e >> 6, 1ull << (e & 63u));
                 } else {
-                    node_pairs<CLOSEST>(nodes, Mg.coord_max, p, pn, qn, vc);
+                    node_pairs<CLOSEST, OBJ>(nodes, Mg.coord_max, p, pn, qn, vc);
                     continue;
                 }
             }
@@ -654,8 +737,8 @@ __device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, un
                     RT_PAIR_ENTRY_EXIT(0, t0, f0, t1, f1);
                     RT_PAIR_ENTRY_EXIT(2, t2, f2, t3, f3);
                     // the loop runs with every lane of the wave enabled, so a compare's lane mask is already the ballot
-                    const unsigned long long m0 = box_lanes(t0, f0, K.limit) & inmask, m1 = box_lanes(t1, f1, K.limit) & inmask;
-                    unsigned long long m2 = box_lanes(t2, f2, K.limit) & inmask, m3 = box_lanes(t3, f3, K.limit) & inmask;
+                    const unsigned long long m0 = box_lanes<CLOSEST && OBJ>(t0, f0, K.limit) & inmask, m1 = box_lanes<CLOSEST && OBJ>(t1, f1, K.limit) & inmask;
+                    unsigned long long m2 = box_lanes<CLOSEST && OBJ>(t2, f2, K.limit) & inmask, m3 = box_lanes<CLOSEST && OBJ>(t3, f3, K.limit) & inmask;
                     if (ref[2] == RT_NO_CHILD) m2 = 0;
                     if (ref[3] == RT_NO_CHILD) m3 = 0;
                     if (CLOSEST) {
@@ -708,6 +791,20 @@ __device__ bool packet_closest_deferred(const DMesh* Mp, const Ray& ray, bool ac
     return mh.n > 0;
 }
 
+// Closest object of the scene's object tree for the wave's rays: nearer than `bound`, or as near with an index below
+// `rank` (scene.rs:57-82: the stable sort keeps the lowest index among equals).  Every lane of the wave must call it.
+__device__ bool packet_closest_objects(const DScene* Sp, const Ray& ray, bool active, double bound, uint32_t rank, double& near, uint32_t& oi, Visits& vc) {
+    park_rays_objects(ray, active, bound, rank);
+    unsigned long long unresolved;
+    packet_deferred<false, true, true>(&Sp->tlas_mesh, vc, 0, unresolved, Sp);
+    wave_lds_sync();
+    const uint32_t at = uni(threadIdx.x >> 6) * 64 + lane_now();
+    const unsigned long long b = rt_qbound[at], b0 = dkey(bound);
+    const uint32_t k = rt_qrank[at];
+    if (active && b != 0 && (b < b0 || (b == b0 && k < rank))) { near = dkey_inv(b); oi = k; return true; }
+    return false;
+}
+
 // Scene::cast_ray_once for a whole wave (scene.rs:57-82): the object loop is uniform, meshes are walked as a
 // packet.  Every lane calls it; `active` lanes carry a ray.
 // FAR = false: the scene has no mesh whose material needs Hit::far, and the lane-by-lane two-hit walk is left out
@@ -715,7 +812,8 @@ __device__ bool packet_closest_deferred(const DMesh* Mp, const Ray& ray, bool ac
 // DEFER: the meshes are walked by packet_closest_deferred (triangle tests and thin ends of the walk set aside)
 // instead of packet_traverse.
 template <bool FAR, bool DEFER = false>
-__device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active, Closest& c, Visits& vc) {
+__device__ bool cast_closest_packet(const DScene* Sp, const Ray& ray, bool active, Closest& c, Visits& vc) {
+    const DScene& S = *Sp;
     c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
     bool any = false;
     const uint32_t n = S.n_linear;
@@ -743,7 +841,17 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
         }
         if (hit && (!any || near < c.t)) { c.obj = oi; c.rank = RT_NONE; c.t = near; any = true; }
     }
-    if (S.n_tlas && active) any = tlas_closest(S, ray, c, any);
+    if (S.n_tlas) {
+        if (DEFER) {
+            // rays whose direction is not of unit length do not cull (tlas_culls): lane by lane, every object
+            const bool culls = tlas_culls(ray);
+            if (active && !culls) any = tlas_closest(S, ray, c, any);
+            double near; uint32_t oi;
+            if (packet_closest_objects(Sp, ray, active && culls, any ? c.t : INFINITY, any ? c.obj : RT_NONE, near, oi, vc)) {
+                c.obj = oi; c.rank = RT_NONE; c.t = near; c.t2 = 0.; c.u = 0.f; c.v = 0.f; any = true;
+            }
+        } else if (active) any = tlas_closest(S, ray, c, any);
+    }
     return any;
 }
 
@@ -753,8 +861,9 @@ __device__ bool cast_closest_packet(const DScene& S, const Ray& ray, bool active
 // With a budget, a wave whose mesh walk runs long gives up: `unresolved` then holds the lanes whose cast is still
 // open, to be cast again piecewise.
 template <bool BUDGET>
-__device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bool limited, double dist, Visits& vc,
+__device__ bool cast_any_packet(const DScene* Sp, const Ray& ray, bool active, bool limited, double dist, Visits& vc,
                                 uint32_t budget, unsigned long long& unresolved) {
+    const DScene& S = *Sp;
     const uint32_t n = S.n_linear;
     const RT_GLOBAL DObject* objs = gptr(S.objects);
     bool blocked = false;
@@ -771,10 +880,18 @@ __device__ bool cast_any_packet(const DScene& S, const Ray& ray, bool active, bo
             if (hit && (!limited || near <= dist)) blocked = true;
         }
     }
-    if (S.n_tlas && active && !blocked) blocked = tlas_any(S, ray, limited, dist);
+    // the object tree: as a packet too, but for rays whose direction is not of unit length (they do not cull, tlas_culls)
+    if (S.n_tlas && active && !blocked && !tlas_culls(ray)) blocked = tlas_any(S, ray, limited, dist);
     if (!__ballot(active && !blocked)) return blocked;
-    const bool open = active && !blocked;   // the lanes whose cast the meshes decide
+    const bool open = active && !blocked;   // the lanes whose cast the object tree and the meshes decide
     park_rays(ray, open, limited ? dist : INFINITY);
+    if (S.n_tlas) {
+        unsigned long long unres = 0;
+        packet_deferred<BUDGET, false, true>(&Sp->tlas_mesh, vc, budget, unres, Sp);
+        const unsigned long long still = __ballot(open && !parked_blocked());
+        if (unres) { unresolved = still; return blocked || (open && parked_blocked()); }
+        if (!still) return blocked || (open && parked_blocked());
+    }
     for (uint32_t li_ = 0; li_ < n; li_++) {
         const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
         const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload);

@@ -124,6 +124,7 @@ struct DScene {
     const DMesh* meshes;
     const DTlasNode* tlas;          // null when the scene has few analytic objects
     const DTlasQuad* tlas_quad;     // the same tree folded four-wide (record 0 = the root)
+    DMesh tlas_mesh;                // the four-wide tree described like a mesh's (nodes, root box, coord_max, root_ref = 0): what the packet walks take
     const uint32_t* linear;         // indices of the objects the casts scan one by one (all that are not in the tree)
     uint32_t n_tlas, n_linear;
     const DMaterial* materials;

@@ -223,7 +223,7 @@ DEV void trace_body(const DScene* Sp, DLevel L, uint32_t n, const unsigned long 
     bool hit = false;
     if (PACKET) {
         // the wave's rays are coherent (primary rays of an 8x8 pixel block) and walk the BVH together
-        hit = cast_closest_packet<FAR, DEFER>(S, ray, active, c, vc);
+        hit = cast_closest_packet<FAR, DEFER>(Sp, ray, active, c, vc);
     } else if (active && !BUDGET) {
         hit = MESHES ? cast_closest<FAR>(S, ray, c, vc) : cast_closest_analytic(S, ray, c);
     } else if (active) {
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene
         if (!have) cast = 0;
         // the wave's shadow rays leave neighbouring hit points towards one light: walked as a packet
         unsigned long long unresolved = 0;
-        const bool blocked = cast_any_packet<BUDGET>(S, ray, cast != 0, limited, dist, vc, lp.budget_wave, unresolved);
+        const bool blocked = cast_any_packet<BUDGET>(Sp, ray, cast != 0, limited, dist, vc, lp.budget_wave, unresolved);
         if (cast) occ[(size_t)li * stride + hitlist[hh]] = blocked ? 1 : 0;
         if (BUDGET && unresolved) {
             // the wave gave up: its open rays go on the long-ray list (k_long_shadow sets their byte when blocked)

@@ -118,6 +118,7 @@ struct rt_ctx {
     bool any_need_far = false;                        // some mesh's material needs Hit::far (transparency with ior == 1)
     bool any_mesh_refracts = false;                   // some mesh has a refracting material (transparency with ior != 1): k_spawn needs the mesh walk
     uint32_t packet_depth = 0;                        // levels 0..packet_depth trace their rays as wave packets
+    uint32_t defer_objects_below = 0;                 // scenes without meshes: levels below this one walk the object tree as deferred packets (the others lane by lane)
     bool defer_small = true;                          // ... also in launches small enough for the long-ray budgets
     uint32_t defer_from = 1;                          // levels from this one on walk meshes as packets with the triangle tests and the thin ends set aside (scenes without need_far meshes)
     bool serial = false;                              // RTGPU_SERIAL=1: everything on the main stream (profiling: kernels do not overlap)
@@ -742,15 +743,19 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
         HIP_TRY(c, hipEventRecord(W.ev[LW_T0], s));
         // depth 0 of a scene with meshes: primary rays, 8x8 pixel blocks per wave -> coherent packets; deeper rays
         // (and scenes of analytic objects only, whose object tree is walked per lane anyway) lane by lane
-        const bool deferred = c->hscene.n_meshes != 0 && !c->any_need_far && depth >= c->defer_from && (!lp.budget_lane || c->defer_small);
+        // (a scene of analytic objects only has no plain packets: its object tree is walked by the deferred packets at
+        // every level, or lane by lane)
+        const bool object_tree_only = c->hscene.n_meshes == 0 && c->hscene.n_tlas != 0 && c->defer_from <= RT_MAX_LEVELS && (uint32_t)depth < c->defer_objects_below;
+        const bool deferred = object_tree_only ||
+                              (c->hscene.n_meshes != 0 && !c->any_need_far && depth >= c->defer_from && (!lp.budget_lane || c->defer_small));
         if (deferred) lp.budget_lane = 0;
         {
             auto launch = [&](auto kern) {
                 hipLaunchKernelGGL(kern, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, n_dev, hitlist, hs, n, dc, lc, long_trace, lp);
             };
             const bool cnt = (c->count_visits & 1) != 0;
-            if (c->hscene.n_meshes == 0) { if (cnt) launch(k_trace<true, false, false, false, false>); else launch(k_trace<false, false, false, false, false>); }
-            else if (deferred) { if (cnt) launch(k_trace_deferred<true>); else launch(k_trace_deferred<false>); }
+            if (deferred) { if (cnt) launch(k_trace_deferred<true>); else launch(k_trace_deferred<false>); }
+            else if (c->hscene.n_meshes == 0) { if (cnt) launch(k_trace<true, false, false, false, false>); else launch(k_trace<false, false, false, false, false>); }
             else if (depth <= c->packet_depth) {   // (packets pay for mesh walks only)
                 if (c->any_need_far) { if (cnt) launch(k_trace_packet<true, true>); else launch(k_trace_packet<false, true>); }
                 else { if (cnt) launch(k_trace_packet<true, false>); else launch(k_trace_packet<false, false>); }
@@ -795,7 +800,7 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
         if (c->n_lights) {
             // sized for the worst case (every ray hit); threads past the hit count leave at once
             const dim3 sgrid((n + RT_BLOCK - 1) / RT_BLOCK, c->n_lights);
-            if (c->hscene.n_meshes == 0) {
+            if (c->hscene.n_meshes == 0 && !(c->hscene.n_tlas != 0 && c->defer_from <= RT_MAX_LEVELS)) {
                 lp.budget_wave = 0;   // (no long-ray pass: nothing is walked as a packet)
                 hipLaunchKernelGGL(k_shadow_lanes<false>, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc);
             } else {
@@ -947,6 +952,7 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         if (const char* b = std::getenv("RTGPU_PACKET_DEPTH")) c->packet_depth = (uint32_t)std::strtoul(b, nullptr, 10);
         if (const char* b = std::getenv("RTGPU_DEFER_FROM")) c->defer_from = (uint32_t)std::strtoul(b, nullptr, 10);
         if (const char* b = std::getenv("RTGPU_DEFER_SMALL")) c->defer_small = b[0] != '0';
+        if (const char* b = std::getenv("RTGPU_DEFER_OBJECTS_BELOW")) c->defer_objects_below = (uint32_t)std::strtoul(b, nullptr, 10);
         if (const char* b = std::getenv("RTGPU_BUDGET_BELOW")) c->long_below = (uint32_t)std::strtoul(b, nullptr, 10);
     }
     for (auto& ev : c->ev) ev = nullptr;
@@ -1155,6 +1161,7 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
         uint32_t tlas_min = 8;
         if (const char* e = std::getenv("RTGPU_TLAS_MIN")) tlas_min = (uint32_t)std::strtoul(e, nullptr, 10);
         H.tlas = nullptr; H.tlas_quad = nullptr; H.n_tlas = 0;
+        std::memset(&H.tlas_mesh, 0, sizeof(H.tlas_mesh));
         if (items.size() >= std::max<uint32_t>(tlas_min, 2)) {
             std::vector<DTlasNode> nodes;
             nodes.reserve(items.size() * 2);
@@ -1197,6 +1204,17 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
             // a step of the walk leaves at most three children waiting
             if (3 * (size_t)quad_depth > RT_MAX_STACK) return fail(c, RT_ERR_UNSUPPORTED, "object tree deeper than the traversal stack");
             if ((rc = upload(c, quads.data(), quads.size(), &H.tlas_quad)) != RT_OK) return rc;
+            // the packet walks take the tree as they take a mesh's: same records, the root's own box, the largest
+            // |coordinate| of any box (it bounds the rounding error of their f32 slab arithmetic)
+            std::memset(&H.tlas_mesh, 0, sizeof(H.tlas_mesh));
+            H.tlas_mesh.nodes = (const DNode*)H.tlas_quad;
+            H.tlas_mesh.n_inner = (uint32_t)quads.size();
+            H.tlas_mesh.root_ref = 0;
+            float cm = 0.f;
+            for (const DTlasNode& nd : nodes) for (int k = 0; k < 3; k++) cm = std::max(cm, std::max(std::fabs(nd.bmin[k]), std::fabs(nd.bmax[k])));
+            H.tlas_mesh.coord_max = cm;
+            for (int k = 0; k < 3; k++) { H.tlas_mesh.root_min[k] = nodes[0].bmin[k]; H.tlas_mesh.root_max[k] = nodes[0].bmax[k]; }
+            if (3 * (size_t)quad_depth > RT_PSTACK) return fail(c, RT_ERR_UNSUPPORTED, "object tree deeper than the packet stack");
         }
     }
     if ((rc = upload(c, objs.data(), objs.size(), &H.objects)) != RT_OK) return rc;

@@ -285,6 +285,31 @@ def spheres_over_terrain_scene(vw=192, vh=108, n=4, cells=24, seed=3):
     return s
 
 
+def overlapping_objects_scene(vw=160, vh=90, seed=5):
+    """Spheres and boxes that overlap each other, the camera and the point light: rays start inside objects, which
+    the reference's sphere test answers with a negative distance (sphere.rs:33-62) and its closest-hit sort then
+    prefers (scene.rs:57-82) -- the case an object tree's walk has to order correctly."""
+    rng = np.random.default_rng(seed)
+    s = Scene()
+    s.set_camera(Camera(vw=vw, vh=vh, origin=(0.2, 0.1, 0.3), yaw=0.3, pitch=-0.1, fov=70.))
+    s.set_options(max_ray_depth=3)
+    s.skybox_normal()
+    s.add_light(sdl_sun((-0.4, -1., -0.3), shadows=True))
+    s.add_light(Point(position=(1.7, 0.4, -1.5), intensity=6.))
+    for i in range(3):
+        for j in range(2):
+            for k in range(3):
+                pos = (1.6 * (i - 1) + float(rng.uniform(-.2, .2)), 1.4 * j - 0.5 + float(rng.uniform(-.2, .2)),
+                       -1.6 * k + float(rng.uniform(-.2, .2)))
+                col = (as_u8(60 + 90 * i), as_u8(80 + 120 * j), as_u8(60 + 90 * k))
+                if (i + j + k) % 4 == 1:
+                    s.add(Aabb(pos, (0.9, 0.8, 1.0), sdl_material(Texture.solid(col), reflectiveness=0.3, transparency=0.5 if k == 1 else 0., ior=1.)))
+                else:
+                    s.add(Sphere(pos, 1.1, sdl_material(Texture.solid(col), reflectiveness=0.4 if i != 1 else 0.,
+                                                        transparency=0.6 if (i + k) % 2 == 0 else 0., ior=1. if j == 0 else 1.3)))
+    return s
+
+
 # The cube of images/readme/10_7_2021.png, fitted (tools/fit_readme_10_7.py): the listing draws it from random()
 README_10_7_BOX = (0.7830276489257812, 0.9763870239257812, -7.986015319824219)
 

@@ -414,12 +414,16 @@ def test_random_scenes_with_long_ray_lists(monkeypatch):
     {"RTGPU_DEFER_FROM": "99"},                                 # level 0 as plain packets, deeper levels lane by lane
     {"RTGPU_DEFER_FROM": "99", "RTGPU_PACKET_DEPTH": "8"},      # every level as plain packets
     {"RTGPU_DEFER_FROM": "0", "RTGPU_NODE_QUEUE": "12"},        # ... with a node queue so short that it keeps overflowing
-], ids=["deferred-from-0", "lane-by-lane", "plain-packets", "short-node-queue"])
+    {"RTGPU_DEFER_OBJECTS_BELOW": "8"},                         # scenes without meshes: the object tree's closest casts as deferred packets too
+    {"RTGPU_DEFER_OBJECTS_BELOW": "8", "RTGPU_NODE_QUEUE": "12", "RTGPU_DEFER_FROM": "0"},
+], ids=["deferred-from-0", "lane-by-lane", "plain-packets", "short-node-queue", "object-packets", "object-packets-short-queue"])
 def test_every_way_of_tracing_a_level_gives_the_same_frame(env, monkeypatch):
     """The closest casts of a level run as plain packets, as packets whose triangle tests and thinly populated nodes
     wait in queues, or lane by lane (the default mixes them by level): random scenes equal the oracle byte for byte
     under each, and so do the icospheres of the reference's README, whose rays through shared edges and vertices hit
-    two or more triangles at exactly the same distance (the lower position in the tree's leaf order must win)."""
+    two or more triangles at exactly the same distance (the lower position in the tree's leaf order must win).  Scenes
+    with eight or more spheres and boxes have an object tree, whose shadow casts are packets always and whose closest
+    casts are on request."""
     from raytracer_amd.scene import read_png
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -428,7 +432,9 @@ def test_every_way_of_tracing_a_level_gives_the_same_frame(env, monkeypatch):
         for seed in range(2000, 2030):
             s, _ = fz.random_scene(seed)
             _assert_identical(ctx, s)
-        for builder, args in ((scenes.synthetic_terrain_scene, (256, 144, 48)), (scenes.terrain_scene, (256, 144, 24, 24))):
+        for builder, args in ((scenes.synthetic_terrain_scene, (256, 144, 48)), (scenes.terrain_scene, (256, 144, 24, 24)),
+                              (scenes.huge_grid_scene, (192, 108, 5)), (scenes.spheres_over_terrain_scene, (192, 108, 4, 24)),
+                              (scenes.overlapping_objects_scene, (160, 90))):
             _assert_identical(ctx, builder(*args))
         for k, order in ((1, 0), (2, 2), (3, 5)):
             ctx.upload(scenes.icosphere_scene(order))
