@@ -247,6 +247,9 @@ __shared__ uint32_t rt_qpair[RT_PWAVES * RT_QCAP];
 #ifndef RT_SPARSE_CLOSEST
 #define RT_SPARSE_CLOSEST RT_SPARSE   /* the same for a closest-hit walk */
 #endif
+#ifndef RT_QFLUSH_OBJ
+#define RT_QFLUSH_OBJ RT_QFLUSH   /* the same for the closest-hit walk of an object tree */
+#endif
 #ifndef RT_NCAP
 #define RT_NCAP 224
 #endif
@@ -593,6 +596,7 @@ __device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, un
     const uint32_t w = uni(threadIdx.x >> 6);
     const uint32_t wq = w * RT_QCAP, wn = w * RT_NCAP;
     const uint32_t ncap = uni(rt_node_cap) < RT_NCAP ? uni(rt_node_cap) : RT_NCAP;
+    const uint32_t qflush = CLOSEST && OBJ ? RT_QFLUSH_OBJ : RT_QFLUSH;
     // Per-lane constants of the box test, as in PRay but filed by role: c_entry goes with the plane the ray meets
     // first along the axis, c_exit with the other.  Which plane that is (min or max) depends on the direction's sign
     // only, and the walk below handles lanes of one sign pattern at a time, so it is settled per walk, not per test.
@@ -686,7 +690,7 @@ __device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, un
             qn = (uint32_t)__popcll(alive);
         } else st.push(root, alive);
         while (true) {
-            if (qn >= RT_QFLUSH || (qn > 0 && st.sp == 0 && pn == 0)) {
+            if (qn >= qflush || (qn > 0 && st.sp == 0 && pn == 0)) {
                 // one round of triangle tests (the one place where triangles are tested, so that the kernel holds that
                 // code once): when 48 pairs wait, or nothing else is left to do
                 const uint32_t cnt = qn < 64 ? qn : 64;
@@ -762,7 +766,7 @@ __device__ void packet_deferred(const DMesh* Mp, Visits& vc, uint32_t budget, un
                         RT_CHILD_ENTERED(ref[1], m1, t1)
                         RT_CHILD_ENTERED(ref[0], m0, t0)   // pushed last: walked first (the order makes no measurable difference)
                     }
-                } while (st.sp > 0 && qn < RT_QFLUSH && pn < RT_NFLUSH);
+                } while (st.sp > 0 && qn < qflush && pn < RT_NFLUSH);
             }
         }
         if (BUDGET && unresolved) { unresolved = alive | remaining; break; }   // out of budget: the lanes still open
