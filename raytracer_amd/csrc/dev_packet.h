@@ -48,59 +48,6 @@ DEV TriData load_utri(const DTri* tris, uint32_t rank) {
     return t;
 }
 
-// Per-lane constants of the packet walk's box test.  The slab distance (b - o) * m is evaluated as
-// fma(b, m, c) with c = -(o * m) rounded to f32: one instruction per plane (two planes with the packed form), one
-// rounding of the result.  Against the exact distance the value is off by at most
-//     2^-24 |o m|  (rounding of c)  +  2^-24 |b m|  (rounding of m)  +  2^-24 |t|  (rounding of the result),
-// and |t| <= (|b| + |o|) |m|, so E = 2^-22 (|o| + B) |m| with B = the largest |coordinate| of the mesh bounds all
-// three.  c is moved outward by E per plane (entry planes down, exit planes up), after which the comparisons need no
-// further slack.  1/direction is clamped to +-1e30 so that an axis-parallel ray gives no inf - inf.
-typedef float __attribute__((ext_vector_type(2))) rt_f2;
-struct PRay { float mx, my, mz, cminx, cminy, cminz, cmaxx, cmaxy, cmaxz; };
-DEV void pray_axis(double o, double m, float B, float& mf, float& cmin, float& cmax) {
-    mf = fminf(fmaxf((float)m, -1e30f), 1e30f);
-    const double om = o * (double)mf;
-    const float slack = (fabsf((float)o) + B) * fabsf(mf) * 2.4e-7f;   // 2^-22, rounded up
-    const float lo = __double2float_rd(-om) - slack, hi = __double2float_ru(-om) + slack;
-    const bool pos = !(mf < 0.f);
-    cmin = pos ? lo : hi;   // the min plane is the entry plane when the ray runs in +axis direction
-    cmax = pos ? hi : lo;
-}
-// The same from the direction itself, without the f64 division: 1/direction as the f32 reciprocal (1 ulp) of the
-// direction rounded to f32, so the slope is off by up to 3 * 2^-24 instead of 2^-24 and the total by 5 * 2^-24
-// (|o| + B) |m|; c is rounded to nearest (that rounding is the first term above) and c -+ slack rounds once more,
-// 6 * 2^-24 in all: the slack is 9 * 2^-24.  (Directed roundings of c would be a dozen instructions each here, and
-// these constants are worked out again after every round of triangle tests.)
-DEV void pray_axis_d(double o, double d, float B, float& mf, float& cmin, float& cmax) {
-    mf = fminf(fmaxf(__builtin_amdgcn_rcpf((float)d), -1e30f), 1e30f);
-    const float c = (float)-(o * (double)mf);
-    const float slack = (fabsf((float)o) + B) * fabsf(mf) * 5.4e-7f;   // 9 * 2^-24, rounded up
-    const float lo = c - slack, hi = c + slack;
-    const bool pos = !(mf < 0.f);
-    cmin = pos ? lo : hi;
-    cmax = pos ? hi : lo;
-}
-DEV PRay pray_new(const Ray& r, float B) {
-    PRay p;
-    pray_axis(r.o.x, r.m.x, B, p.mx, p.cminx, p.cmaxx);
-    pray_axis(r.o.y, r.m.y, B, p.my, p.cminy, p.cmaxy);
-    pray_axis(r.o.z, r.m.z, B, p.mz, p.cminz, p.cmaxz);
-    return p;
-}
-// children k and k+1 of a uniform node against this lane's ray: entry and exit distance of each
-#define RT_CHILD_PAIR(n, k, tn_a, tf_a, tn_b, tf_b)                                                                        \
-    do {                                                                                                                  \
-        const rt_f2 lx_ = __builtin_elementwise_fma(rt_f2{asf((n).minx[k]), asf((n).minx[k + 1])}, rt_f2{pr.mx, pr.mx}, rt_f2{pr.cminx, pr.cminx}); \
-        const rt_f2 hx_ = __builtin_elementwise_fma(rt_f2{asf((n).maxx[k]), asf((n).maxx[k + 1])}, rt_f2{pr.mx, pr.mx}, rt_f2{pr.cmaxx, pr.cmaxx}); \
-        const rt_f2 ly_ = __builtin_elementwise_fma(rt_f2{asf((n).miny[k]), asf((n).miny[k + 1])}, rt_f2{pr.my, pr.my}, rt_f2{pr.cminy, pr.cminy}); \
-        const rt_f2 hy_ = __builtin_elementwise_fma(rt_f2{asf((n).maxy[k]), asf((n).maxy[k + 1])}, rt_f2{pr.my, pr.my}, rt_f2{pr.cmaxy, pr.cmaxy}); \
-        const rt_f2 lz_ = __builtin_elementwise_fma(rt_f2{asf((n).minz[k]), asf((n).minz[k + 1])}, rt_f2{pr.mz, pr.mz}, rt_f2{pr.cminz, pr.cminz}); \
-        const rt_f2 hz_ = __builtin_elementwise_fma(rt_f2{asf((n).maxz[k]), asf((n).maxz[k + 1])}, rt_f2{pr.mz, pr.mz}, rt_f2{pr.cmaxz, pr.cmaxz}); \
-        (tn_a) = fmaxf(fmaxf(fminf(lx_.x, hx_.x), fminf(ly_.x, hy_.x)), fminf(lz_.x, hz_.x));                              \
-        (tf_a) = fminf(fminf(fmaxf(lx_.x, hx_.x), fmaxf(ly_.x, hy_.x)), fmaxf(lz_.x, hz_.x));                              \
-        (tn_b) = fmaxf(fmaxf(fminf(lx_.y, hx_.y), fminf(ly_.y, hy_.y)), fminf(lz_.y, hz_.y));                              \
-        (tf_b) = fminf(fminf(fmaxf(lx_.y, hx_.y), fmaxf(ly_.y, hy_.y)), fmaxf(lz_.y, hz_.y));                              \
-    } while (0)
 // lanes (of the whole wave) whose ray meets the box before `limit`: entry <= exit, exit >= 0, entry <= limit.
 // Every value is finite (finite boxes, clamped 1/direction), so the ordered compare needs no NaN case.
 #define RT_FCMP_OLE 5

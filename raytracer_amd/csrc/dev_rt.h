@@ -238,7 +238,81 @@ DEV bool node_box(FP bmin, FP bmax, const Ray& ray, float& tn_out) {
     return node_box2(bmin, bmax, ray, tn_out, tf);
 }
 
-// mesh.rs:25-59 with the edges precomputed
+// Per-lane constants of the packet walk's box test.  The slab distance (b - o) * m is evaluated as
+// fma(b, m, c) with c = -(o * m) rounded to f32: one instruction per plane (two planes with the packed form), one
+// rounding of the result.  Against the exact distance the value is off by at most
+//     2^-24 |o m|  (rounding of c)  +  2^-24 |b m|  (rounding of m)  +  2^-24 |t|  (rounding of the result),
+// and |t| <= (|b| + |o|) |m|, so E = 2^-22 (|o| + B) |m| with B = the largest |coordinate| of the mesh bounds all
+// three.  c is moved outward by E per plane (entry planes down, exit planes up), after which the comparisons need no
+// further slack.  1/direction is clamped to +-1e30 so that an axis-parallel ray gives no inf - inf.
+typedef float __attribute__((ext_vector_type(2))) rt_f2;
+struct PRay { float mx, my, mz, cminx, cminy, cminz, cmaxx, cmaxy, cmaxz; };
+DEV void pray_axis(double o, double m, float B, float& mf, float& cmin, float& cmax) {
+    mf = fminf(fmaxf((float)m, -1e30f), 1e30f);
+    const double om = o * (double)mf;
+    const float slack = (fabsf((float)o) + B) * fabsf(mf) * 2.4e-7f;   // 2^-22, rounded up
+    const float lo = __double2float_rd(-om) - slack, hi = __double2float_ru(-om) + slack;
+    const bool pos = !(mf < 0.f);
+    cmin = pos ? lo : hi;   // the min plane is the entry plane when the ray runs in +axis direction
+    cmax = pos ? hi : lo;
+}
+// The same from the direction itself, without the f64 division: 1/direction as the f32 reciprocal (1 ulp) of the
+// direction rounded to f32, so the slope is off by up to 3 * 2^-24 instead of 2^-24 and the total by 5 * 2^-24
+// (|o| + B) |m|; c is rounded to nearest (that rounding is the first term above) and c -+ slack rounds once more,
+// 6 * 2^-24 in all: the slack is 9 * 2^-24.  (Directed roundings of c would be a dozen instructions each here, and
+// these constants are worked out again after every round of triangle tests.)
+DEV void pray_axis_d(double o, double d, float B, float& mf, float& cmin, float& cmax) {
+    mf = fminf(fmaxf(__builtin_amdgcn_rcpf((float)d), -1e30f), 1e30f);
+    const float c = (float)-(o * (double)mf);
+    const float slack = (fabsf((float)o) + B) * fabsf(mf) * 5.4e-7f;   // 9 * 2^-24, rounded up
+    const float lo = c - slack, hi = c + slack;
+    const bool pos = !(mf < 0.f);
+    cmin = pos ? lo : hi;
+    cmax = pos ? hi : lo;
+}
+DEV PRay pray_new_d(const D3& o, const D3& d, float B) {
+    PRay p;
+    pray_axis_d(o.x, d.x, B, p.mx, p.cminx, p.cmaxx);
+    pray_axis_d(o.y, d.y, B, p.my, p.cminy, p.cmaxy);
+    pray_axis_d(o.z, d.z, B, p.mz, p.cminz, p.cmaxz);
+    return p;
+}
+DEV PRay pray_new(const Ray& r, float B) {
+    PRay p;
+    pray_axis(r.o.x, r.m.x, B, p.mx, p.cminx, p.cmaxx);
+    pray_axis(r.o.y, r.m.y, B, p.my, p.cminy, p.cmaxy);
+    pray_axis(r.o.z, r.m.z, B, p.mz, p.cminz, p.cmaxz);
+    return p;
+}
+// children k and k+1 of a uniform node against this lane's ray: entry and exit distance of each
+#define RT_CHILD_PAIR(n, k, tn_a, tf_a, tn_b, tf_b)                                                                        \
+    do {                                                                                                                  \
+        const rt_f2 lx_ = __builtin_elementwise_fma(rt_f2{asf((n).minx[k]), asf((n).minx[k + 1])}, rt_f2{pr.mx, pr.mx}, rt_f2{pr.cminx, pr.cminx}); \
+        const rt_f2 hx_ = __builtin_elementwise_fma(rt_f2{asf((n).maxx[k]), asf((n).maxx[k + 1])}, rt_f2{pr.mx, pr.mx}, rt_f2{pr.cmaxx, pr.cmaxx}); \
+        const rt_f2 ly_ = __builtin_elementwise_fma(rt_f2{asf((n).miny[k]), asf((n).miny[k + 1])}, rt_f2{pr.my, pr.my}, rt_f2{pr.cminy, pr.cminy}); \
+        const rt_f2 hy_ = __builtin_elementwise_fma(rt_f2{asf((n).maxy[k]), asf((n).maxy[k + 1])}, rt_f2{pr.my, pr.my}, rt_f2{pr.cmaxy, pr.cmaxy}); \
+        const rt_f2 lz_ = __builtin_elementwise_fma(rt_f2{asf((n).minz[k]), asf((n).minz[k + 1])}, rt_f2{pr.mz, pr.mz}, rt_f2{pr.cminz, pr.cminz}); \
+        const rt_f2 hz_ = __builtin_elementwise_fma(rt_f2{asf((n).maxz[k]), asf((n).maxz[k + 1])}, rt_f2{pr.mz, pr.mz}, rt_f2{pr.cmaxz, pr.cmaxz}); \
+        (tn_a) = fmaxf(fmaxf(fminf(lx_.x, hx_.x), fminf(ly_.x, hy_.x)), fminf(lz_.x, hz_.x));                              \
+        (tf_a) = fminf(fminf(fmaxf(lx_.x, hx_.x), fmaxf(ly_.x, hy_.x)), fmaxf(lz_.x, hz_.x));                              \
+        (tn_b) = fmaxf(fmaxf(fminf(lx_.y, hx_.y), fminf(ly_.y, hy_.y)), fminf(lz_.y, hz_.y));                              \
+        (tf_b) = fminf(fminf(fmaxf(lx_.y, hx_.y), fmaxf(ly_.y, hy_.y)), fmaxf(lz_.y, hz_.y));                              \
+    } while (0)
+// the same for a record whose planes are float arrays (a lane's own record, fetched by vector loads)
+#define RT_CHILD_PAIR_F(n, k, tn_a, tf_a, tn_b, tf_b)                                                                      \
+    do {                                                                                                                  \
+        const rt_f2 lx_ = __builtin_elementwise_fma(rt_f2{(n).minx[k], (n).minx[k + 1]}, rt_f2{pr.mx, pr.mx}, rt_f2{pr.cminx, pr.cminx}); \
+        const rt_f2 hx_ = __builtin_elementwise_fma(rt_f2{(n).maxx[k], (n).maxx[k + 1]}, rt_f2{pr.mx, pr.mx}, rt_f2{pr.cmaxx, pr.cmaxx}); \
+        const rt_f2 ly_ = __builtin_elementwise_fma(rt_f2{(n).miny[k], (n).miny[k + 1]}, rt_f2{pr.my, pr.my}, rt_f2{pr.cminy, pr.cminy}); \
+        const rt_f2 hy_ = __builtin_elementwise_fma(rt_f2{(n).maxy[k], (n).maxy[k + 1]}, rt_f2{pr.my, pr.my}, rt_f2{pr.cmaxy, pr.cmaxy}); \
+        const rt_f2 lz_ = __builtin_elementwise_fma(rt_f2{(n).minz[k], (n).minz[k + 1]}, rt_f2{pr.mz, pr.mz}, rt_f2{pr.cminz, pr.cminz}); \
+        const rt_f2 hz_ = __builtin_elementwise_fma(rt_f2{(n).maxz[k], (n).maxz[k + 1]}, rt_f2{pr.mz, pr.mz}, rt_f2{pr.cmaxz, pr.cmaxz}); \
+        (tn_a) = fmaxf(fmaxf(fminf(lx_.x, hx_.x), fminf(ly_.x, hy_.x)), fminf(lz_.x, hz_.x));                              \
+        (tf_a) = fminf(fminf(fmaxf(lx_.x, hx_.x), fmaxf(ly_.x, hy_.x)), fmaxf(lz_.x, hz_.x));                              \
+        (tn_b) = fmaxf(fmaxf(fminf(lx_.y, hx_.y), fminf(ly_.y, hy_.y)), fminf(lz_.y, hz_.y));                              \
+        (tf_b) = fminf(fminf(fmaxf(lx_.y, hx_.y), fmaxf(ly_.y, hy_.y)), fmaxf(lz_.y, hz_.y));                              \
+    } while (0)
+
 // mesh.rs:25-59 with the edges precomputed.  The 80-byte record is fetched as five 16-byte loads (one L1 tag
 // lookup each) rather than field by field.
 typedef double __attribute__((ext_vector_type(2))) rt_d2;
@@ -349,6 +423,7 @@ __device__ bool mesh_traverse_seg(const DMesh& M, const Ray& ray, double bound, 
     // boxes entered beyond `limit` cannot hold the answer; kept in f32, rounded up so that the skip stays safe
     float limit = limit_up(bound);
     const float INF = __uint_as_float(0x7F800000u);
+    const PRay pr = pray_new_d(ray.o, ray.d, M.coord_max);   // the boxes as one packed FMA per two planes, slack in the constants
 
     while (cur != RT_POP) {
         // ---- inner nodes, until this lane holds a leaf (the lanes of a wave leave this loop together, so
@@ -357,22 +432,17 @@ __device__ bool mesh_traverse_seg(const DMesh& M, const Ray& ray, double bound, 
             const GNodePtr nd = &nodes[cur];
             vc.nodes++; vc.units += 7;
             if (SEG && seg.budget && ++steps > seg.budget) { aborted = true; return false; }
-            float t0, t1, t2, t3;
-            // near/far plane of each child on each axis, by the sign of the direction
-            float f0, f1, f2, f3;
-            bool h0 = slab_test2(ray.nx ? nd->maxx[0] : nd->minx[0], ray.ny ? nd->maxy[0] : nd->miny[0], ray.nz ? nd->maxz[0] : nd->minz[0],
-                                 ray.nx ? nd->minx[0] : nd->maxx[0], ray.ny ? nd->miny[0] : nd->maxy[0], ray.nz ? nd->minz[0] : nd->maxz[0], ray, t0, f0);
-            bool h1 = slab_test2(ray.nx ? nd->maxx[1] : nd->minx[1], ray.ny ? nd->maxy[1] : nd->miny[1], ray.nz ? nd->maxz[1] : nd->minz[1],
-                                 ray.nx ? nd->minx[1] : nd->maxx[1], ray.ny ? nd->miny[1] : nd->maxy[1], ray.nz ? nd->minz[1] : nd->maxz[1], ray, t1, f1);
-            bool h2 = slab_test2(ray.nx ? nd->maxx[2] : nd->minx[2], ray.ny ? nd->maxy[2] : nd->miny[2], ray.nz ? nd->maxz[2] : nd->minz[2],
-                                 ray.nx ? nd->minx[2] : nd->maxx[2], ray.ny ? nd->miny[2] : nd->maxy[2], ray.nz ? nd->minz[2] : nd->maxz[2], ray, t2, f2);
-            bool h3 = slab_test2(ray.nx ? nd->maxx[3] : nd->minx[3], ray.ny ? nd->maxy[3] : nd->miny[3], ray.nz ? nd->maxz[3] : nd->minz[3],
-                                 ray.nx ? nd->minx[3] : nd->maxx[3], ray.ny ? nd->miny[3] : nd->maxy[3], ray.nz ? nd->minz[3] : nd->maxz[3], ray, t3, f3);
+            float t0, t1, t2, t3, f0, f1, f2, f3;
+            RT_CHILD_PAIR_F((*nd), 0, t0, f0, t1, f1);
+            RT_CHILD_PAIR_F((*nd), 2, t2, f2, t3, f3);
+            bool h0 = !(t0 > f0 || f0 < 0.f), h1 = !(t1 > f1 || f1 < 0.f), h2 = !(t2 > f2 || f2 < 0.f), h3 = !(t3 > f3 || f3 < 0.f);
             if (SEG) {
                 h0 = h0 && !(t0 > seg.hi) && !(f0 < seg.lo); h1 = h1 && !(t1 > seg.hi) && !(f1 < seg.lo);
                 h2 = h2 && !(t2 > seg.hi) && !(f2 < seg.lo); h3 = h3 && !(t3 > seg.hi) && !(f3 < seg.lo);
             }
             uint32_t r0 = nd->ref[0], r1 = nd->ref[1], r2 = nd->ref[2], r3 = nd->ref[3];
+            if (r2 == RT_NO_CHILD) h2 = false;
+            if (r3 == RT_NO_CHILD) h3 = false;
             // a child that is missed, entered beyond the limit, or absent sorts last with distance +inf
             t0 = (h0 && !(t0 > limit)) ? t0 : INF;
             t1 = (h1 && !(t1 > limit)) ? t1 : INF;
@@ -567,18 +637,25 @@ __device__ bool tlas_any(const DScene& S, const Ray& ray, bool limited, double d
     }
     return false;
 }
-// One child of a four-wide record: its entry distance if the ray enters its box no later than `limit`, +inf if not (or
-// if the slot is unused); without culling every child counts as entered at -inf.
-#define RT_TQ_CHILD(k, t_)                                                                                                   \
-    do {                                                                                                                     \
-        if (W.ref[k] == RT_TLAS_NONE) (t_) = INF;                                                                            \
-        else if (!cull) (t_) = -INF;                                                                                         \
-        else {                                                                                                               \
-            float tn_;                                                                                                       \
-            const bool h_ = slab_test(ray.nx ? W.maxx[k] : W.minx[k], ray.ny ? W.maxy[k] : W.miny[k], ray.nz ? W.maxz[k] : W.minz[k], \
-                                      ray.nx ? W.minx[k] : W.maxx[k], ray.ny ? W.miny[k] : W.maxy[k], ray.nz ? W.minz[k] : W.maxz[k], ray, tn_); \
-            (t_) = (h_ && !(tn_ > limit)) ? tn_ : INF;                                                                       \
-        }                                                                                                                    \
+// The four children of a four-wide record: each one's entry distance if the ray enters its box no later than `limit`,
+// +inf if not (or if the slot is unused); without culling every child counts as entered at -inf.  (pr: the lane's
+// PRay for the tree; one packed FMA per two planes, the rounding slack folded into its constants.)
+#define RT_TQ_CHILDREN(t0_, t1_, t2_, t3_)                                                                                 \
+    do {                                                                                                                  \
+        if (!cull) { (t0_) = (t1_) = (t2_) = (t3_) = -INF; }                                                              \
+        else {                                                                                                            \
+            float f0_, f1_, f2_, f3_;                                                                                     \
+            RT_CHILD_PAIR_F(W, 0, t0_, f0_, t1_, f1_);                                                                    \
+            RT_CHILD_PAIR_F(W, 2, t2_, f2_, t3_, f3_);                                                                    \
+            (t0_) = (!((t0_) > f0_ || f0_ < 0.f) && !((t0_) > limit)) ? (t0_) : INF;                                      \
+            (t1_) = (!((t1_) > f1_ || f1_ < 0.f) && !((t1_) > limit)) ? (t1_) : INF;                                      \
+            (t2_) = (!((t2_) > f2_ || f2_ < 0.f) && !((t2_) > limit)) ? (t2_) : INF;                                      \
+            (t3_) = (!((t3_) > f3_ || f3_ < 0.f) && !((t3_) > limit)) ? (t3_) : INF;                                      \
+        }                                                                                                                 \
+        if (W.ref[0] == RT_TLAS_NONE) (t0_) = INF;                                                                        \
+        if (W.ref[1] == RT_TLAS_NONE) (t1_) = INF;                                                                        \
+        if (W.ref[2] == RT_TLAS_NONE) (t2_) = INF;                                                                        \
+        if (W.ref[3] == RT_TLAS_NONE) (t3_) = INF;                                                                        \
     } while (0)
 // compare-exchange of (distance, reference, leaf word) triples: afterwards ta <= tb
 #define RT_CSWAP3(ta, ra, wa, tb, rb, wb)                                     \
@@ -610,6 +687,7 @@ __device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c
     float limit = any ? limit_up(c.t) : INF;
     float tn_root = -INF;
     if (cull && !(node_box(nodes[0].bmin, nodes[0].bmax, ray, tn_root) && !(tn_root > limit))) return any;
+    const PRay pr = pray_new_d(ray.o, ray.d, S.tlas_mesh.coord_max);
     // an object reached through a leaf reference: nearest by `near`, ties to the lower index
     auto object = [&](uint32_t oi, uint32_t what) {
         double near;
@@ -622,7 +700,7 @@ __device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c
     while (true) {
         RT_TQ_LOAD(cur);
         float t0, t1, t2, t3;
-        RT_TQ_CHILD(0, t0); RT_TQ_CHILD(1, t1); RT_TQ_CHILD(2, t2); RT_TQ_CHILD(3, t3);
+        RT_TQ_CHILDREN(t0, t1, t2, t3);
         uint32_t r0 = W.ref[0], r1 = W.ref[1], r2 = W.ref[2], r3 = W.ref[3];
         uint32_t w0 = W.what[0], w1 = W.what[1], w2 = W.what[2], w3 = W.what[3];
         RT_CSWAP3(t0, r0, w0, t1, r1, w1); RT_CSWAP3(t2, r2, w2, t3, r3, w3);
@@ -791,11 +869,12 @@ __device__ bool tlas_any_ordered(const DScene& S, const Ray& ray, bool limited, 
     const float limit = limited ? limit_up(dist) : INF;
     float tn_root = -INF;
     if (cull && !(node_box(nodes[0].bmin, nodes[0].bmax, ray, tn_root) && !(tn_root > limit))) return false;
+    const PRay pr = pray_new_d(ray.o, ray.d, S.tlas_mesh.coord_max);
     uint32_t cur = 0;
     while (true) {
         RT_TQ_LOAD(cur);
         float t0, t1, t2, t3;
-        RT_TQ_CHILD(0, t0); RT_TQ_CHILD(1, t1); RT_TQ_CHILD(2, t2); RT_TQ_CHILD(3, t3);
+        RT_TQ_CHILDREN(t0, t1, t2, t3);
         double near;
 #define RT_TQ_LEAF(k, t_)                                                                                   \
         if ((t_) < INF && (W.ref[k] & RT_TLAS_LEAF)) {                                                      \
@@ -819,7 +898,7 @@ __device__ bool tlas_any_ordered(const DScene& S, const Ray& ray, bool limited, 
     }
     return false;
 }
-#undef RT_TQ_CHILD
+#undef RT_TQ_CHILDREN
 #undef RT_TQ_LOAD
 
 // Shadow cast of one lane in a scene without meshes (sun.rs:89: any object the ray hits at all; point.rs:91-92: the
