@@ -1162,7 +1162,8 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
             for (int k = 0; k < 3; k++) finite = finite && std::isfinite(it.lo[k]) && std::isfinite(it.hi[k]);
             // an object with a NaN / infinite extent stays in the linear scan (and so does one whose index would not fit
             // beside the flag bit of a leaf record)
-            if (finite && o.payload < RT_TLAS_BOX) items.push_back(it);
+            // (... or beside the lane number of a queued (object, ray) pair)
+            if (finite && o.payload < RT_TLAS_BOX && i < RT_PACKET_MAX_PRIMS) items.push_back(it);
         }
         uint32_t tlas_min = 8;
         if (const char* e = std::getenv("RTGPU_TLAS_MIN")) tlas_min = (uint32_t)std::strtoul(e, nullptr, 10);
