@@ -234,8 +234,10 @@ const char* rt_last_error(const rt_ctx* ctx);
 
 /* Deep-copies the scene to the device, re-emitting each mesh's top-down BVH
  * (acceleration.rs:407-448) in the device layout.  May be called again per
- * frame (sdl/src/main.rs:84-92 sequence mode).  RT_ERR_UNSUPPORTED for area
- * lights or a BVH deeper than the traversal stack. */
+ * frame (sdl/src/main.rs:84-92 sequence mode).  A mesh tree too deep for the
+ * traversal stacks (about 64 levels) is replaced by a balanced tree over the
+ * same leaves in the same order: same hits, same winners between equal
+ * distances.  RT_ERR_UNSUPPORTED for area lights. */
 int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* scene);
 
 /* Replaces Scene::render (scene.rs:220-246).

@@ -328,7 +328,49 @@ int refit_mesh(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc) {
     return RT_OK;
 }
 
-int upload_mesh(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc) {
+// A caller's tree that is too deep for the traversal stacks is not walked as it stands: its leaves, in the tree's own
+// depth-first order, get a new binary tree above them, split by leaf count (depth log2 of the leaf count), each node's
+// box the union of its leaves' boxes -- what the reference's node boxes are (acceleration.rs:386-400,419-433).  The
+// reference recurses to any depth; what it finds does not depend on the shape of the tree: a triangle that is hit lies
+// in its leaf's box and so in every box above it, in any tree, and between equal distances the lower place in the
+// leaf order wins, which is kept.  (A lopsided tree culls badly whatever walks it; a balanced one over the same
+// leaves is no worse.)  Out: nodes in the layout of rt_mesh::nodes (first child = next record).
+static void rebalance_tree(const rt_mesh& m, std::vector<rt_bvh_node>& out) {
+    std::vector<uint32_t> leaves;
+    {
+        std::vector<uint32_t> st;
+        st.push_back(0u);
+        while (!st.empty()) {
+            const uint32_t i = st.back(); st.pop_back();
+            const rt_bvh_node& nd = m.nodes[i];
+            if (nd.count != 0) { leaves.push_back(i); continue; }
+            st.push_back(nd.right_or_first);
+            st.push_back(i + 1);
+        }
+    }
+    out.clear();
+    out.reserve(leaves.size() * 2);
+    std::function<uint32_t(size_t, size_t)> build = [&](size_t lo, size_t hi) -> uint32_t {
+        const uint32_t me = (uint32_t)out.size();
+        if (hi - lo == 1) { out.push_back(m.nodes[leaves[lo]]); return me; }
+        out.emplace_back();
+        const size_t mid = lo + (hi - lo + 1) / 2;
+        build(lo, mid);                                  // lands at me + 1
+        const uint32_t right = build(mid, hi);
+        rt_bvh_node nd;
+        for (int k = 0; k < 3; k++) {
+            nd.min[k] = std::fmin(out[me + 1].min[k], out[right].min[k]);
+            nd.max[k] = std::fmax(out[me + 1].max[k], out[right].max[k]);
+        }
+        nd.right_or_first = right; nd.count = 0;
+        out[me] = nd;
+        return me;
+    };
+    build(0, leaves.size());
+}
+
+int upload_mesh(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc, bool rebalanced = false);
+int upload_mesh(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc, bool rebalanced) {
     if (!m.nodes && m.n_nodes == 0) return build_mesh_on_device(c, m, mc);
     DMesh& out = mc.dm;
     std::memset(&out, 0, sizeof(out));
@@ -373,9 +415,21 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc) {
             }
         }
     }
-    if (max_depth > RT_MAX_STACK) return fail(c, RT_ERR_UNSUPPORTED, "mesh BVH deeper than the traversal stack (" + std::to_string(max_depth) + " > " + std::to_string(RT_MAX_STACK) + ")");
-    for (uint32_t i = 0; i < NN; i++) if (seen[i] && m.nodes[i].count == 0) inner_id[i] = n_inner++;
     for (uint32_t i = 0; i < m.n_prims; i++) if (m.prim_indices[i] >= m.n_tris) return fail(c, RT_ERR_INVALID, "mesh BVH: primitive index out of range");
+    // too deep for the stacks (here, or for the packet walk's below): the same leaves under a balanced tree
+    auto with_balanced_tree = [&]() {
+        std::vector<rt_bvh_node> nn;
+        rebalance_tree(m, nn);
+        rt_mesh mm = m;
+        mm.nodes = nn.data(); mm.n_nodes = (uint32_t)nn.size();
+        if (dbg) std::fprintf(stderr, "  upload_mesh: tree of depth %u put under a balanced one (%zu nodes)\n", max_depth, nn.size());
+        return upload_mesh(c, mm, mc, true);
+    };
+    if (max_depth > RT_MAX_STACK) {
+        if (rebalanced) return fail(c, RT_ERR_UNSUPPORTED, "mesh BVH deeper than the traversal stack (" + std::to_string(max_depth) + " > " + std::to_string(RT_MAX_STACK) + ")");
+        return with_balanced_tree();
+    }
+    for (uint32_t i = 0; i < NN; i++) if (seen[i] && m.nodes[i].count == 0) inner_id[i] = n_inner++;
 
     lap("validate");
     // f32 box of node i, rounded outward from the slab bounds the reference's test uses:
@@ -479,8 +533,10 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc) {
         }
     });
     lap("collapse");
-    if (pstack_need > RT_PSTACK)
-        return fail(c, RT_ERR_UNSUPPORTED, "mesh BVH needs " + std::to_string(pstack_need) + " packet stack entries (limit " + std::to_string(RT_PSTACK) + ")");
+    if (pstack_need > RT_PSTACK) {
+        if (rebalanced) return fail(c, RT_ERR_UNSUPPORTED, "mesh BVH needs " + std::to_string(pstack_need) + " packet stack entries (limit " + std::to_string(RT_PSTACK) + ")");
+        return with_balanced_tree();
+    }
     if (m.n_prims > RT_PACKET_MAX_PRIMS)
         return fail(c, RT_ERR_UNSUPPORTED, "mesh BVH with more than " + std::to_string(RT_PACKET_MAX_PRIMS) + " leaf entries");
     if (std::getenv("RTGPU_DEBUG_BVH")) std::fprintf(stderr, "binary depth %u, wide nodes %u, packet stack %u\n", max_depth, n_inner, pstack_need);

@@ -533,8 +533,9 @@ def _spine_mesh(levels, seed=9):
 
 
 def test_lopsided_tree_fills_the_packet_stack(gpu_ctx):
-    """A caller-built tree close to the limit of the wave-uniform stack renders like the oracle; one beyond it is
-    refused at upload instead of overrunning the stack."""
+    """A caller-built tree close to the limit of the wave-uniform stack renders like the oracle; so do trees beyond it,
+    which the reference walks by recursion (mesh.rs:326-345) and upload puts under a balanced tree over the same
+    leaves instead of overrunning a stack."""
     def scene_with(mesh):
         s = ra.Scene()
         s.set_camera(ra.Camera(vw=96, vh=64, origin=(0.05, 1.1, 7.0), yaw=0.01, pitch=-0.02))
@@ -552,9 +553,13 @@ def test_lopsided_tree_fills_the_packet_stack(gpu_ctx):
     assert_parity(rgb, ids, o_rgb, o_ids)
     assert ray_counts(st) == ray_counts(o_st) and st.rays_shadow > 0
 
-    with pytest.raises(N.RtError) as e:
-        gpu_ctx.upload(scene_with(_spine_mesh(56)))
-    assert e.value.code == N.RT_ERR_UNSUPPORTED and "stack" in str(e.value)
+    for levels in (56, 180):
+        s = scene_with(_spine_mesh(levels))
+        gpu_ctx.upload(s)
+        rgb, ids, st = gpu_ctx.render(ids=True)
+        o_rgb, o_ids, o_st, _ = oracle.render(s, 0)
+        assert_parity(rgb, ids, o_rgb, o_ids, exact_floor=1.0)
+        assert ray_counts(st) == ray_counts(o_st) and st.rays_shadow > 0
 
 
 def test_speculative_frames_equal_measured_ones_and_fall_back_when_a_level_outgrows_its_room(monkeypatch):
