@@ -85,8 +85,18 @@ def lib():
         L.orc_skybox_ray_color.restype = None
         L.orc_powi.argtypes = [C.c_double, C.c_int]
         L.orc_powi.restype = C.c_double
+        L.orc_set_area_seed.argtypes = [C.c_uint64]
+        L.orc_set_area_seed.restype = None
         _lib = L
     return _lib
+
+
+DEFAULT_AREA_SEED = 0x9E3779B97F4A7C15
+
+
+def set_area_seed(seed=DEFAULT_AREA_SEED):
+    """Seed of the stand-in for area.rs:121's unseeded generator, for the renders that follow."""
+    lib().orc_set_area_seed(seed)
 
 
 def render(scene, n_threads=0, pixels=None, ids=True):

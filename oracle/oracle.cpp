@@ -697,9 +697,14 @@ void fill_stats(const Counts& c, rt_stats* s, orc_counts* oc) {
     }
 }
 
+/* seed of the stand-in generator above; tests vary it to learn how far the draws move a pixel */
+std::atomic<uint64_t> g_area_seed{0x9E3779B97F4A7C15ull};
+
 }  // namespace
 
 extern "C" {
+
+void orc_set_area_seed(uint64_t seed) { g_area_seed.store(seed); }
 
 /* scene.rs:220-246 over an explicit pixel list (pixel index i = y*vw + x, the
  * reference's own linear index); pixels == NULL renders 0..n in order. */
@@ -715,7 +720,7 @@ int rt_cpu_render_pixels(const rt_scene_desc* d, int n_threads, uint64_t n, cons
     if (pixels) { for (uint64_t k = 0; k < n; k++) if (pixels[k] >= total) return RT_ERR_INVALID; }
     else if (n > total) return RT_ERR_INVALID;
 
-    Scene sc{d, 0x9E3779B97F4A7C15ull};
+    Scene sc{d, g_area_seed.load()};
     const uint64_t chunk = 256;
     std::atomic<uint64_t> next{0};
     std::vector<Counts> counts((size_t)n_threads);

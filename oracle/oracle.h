@@ -43,6 +43,8 @@ double orc_camera_chf(double fov);
 void orc_texture_at(const rt_texture* t, float u, float v, uint8_t* out);
 void orc_skybox_ray_color(const rt_skybox* sb, const double* d, uint8_t* out);
 double orc_powi(double a, int b);
+/* area.rs:121 draws from an unseeded generator; the checker's stand-in is seeded, and this sets the seed of later renders */
+void orc_set_area_seed(uint64_t seed);
 
 #ifdef __cplusplus
 }
