@@ -96,7 +96,7 @@ def refraction_scene(vw=1920, vh=1080, cubemap=None):
     s.add(sdl_plane((0., -1., 0.)))
     s.set_camera(Camera(vw=vw, vh=vh, yaw=0.0001, pitch=0.0002))
     s.skybox_cubemap(cubemap if cubemap is not None else procedural_cubemap(256))
-    s.add(Sphere((0., 0., -5.), 1., sdl_material(transparency=0.6, reflectiveness=0.5, ior=glass_ior)))
+    s.add(Sphere((0., 0., -5.), 1., sdl_material(transparency=0.6, reflectiveness=0.5)))
     s.add(Sphere((-1., 0., -9.), 1., sdl_material(Texture.solid((255, 0, 0)), reflectiveness=0.2)))
     s.add(Sphere((1.0, 0., -9.), 1., sdl_material(Texture.solid((0, 0, 255)), reflectiveness=0.2)))
     return s
@@ -177,7 +177,7 @@ def synthetic_terrain_scene(vw=3840, vh=2160, cells=708, n_lights=8, seed=42, de
     sdl_mesh(mesh, position=(0., 0., 0.), device_bvh=device_bvh)           # recentred on the origin
     s.add(mesh)
     s.mesh = s.mesh_at(0)
-    s.add(Sphere((0., extent * 0.06, 0.), extent * 0.04, sdl_material(transparency=0.6, reflectiveness=0.5, ior=glass_ior)))
+    s.add(Sphere((0., extent * 0.06, 0.), extent * 0.04, sdl_material(transparency=0.6, reflectiveness=0.5)))
     s.skybox_solid((30, 40, 70))
     ring_r, ring_h = extent * 0.28, extent * 0.085
     for k in range(n_lights):
@@ -243,7 +243,7 @@ def small_mixed_scene(vw=160, vh=120, cells=24, seed=5, device_bvh=False):
     s.add(mesh)
     s.mesh = s.mesh_at(0)
     s.add(sdl_plane((0., -2., 0.), material=sdl_material(Texture.checkerboard((255, 255, 255), (60, 60, 60)), reflectiveness=0.2), uv_wrap=2.))
-    s.add(Sphere((0., 1.5, 1.), 1., sdl_material(transparency=0.6, reflectiveness=0.5, ior=glass_ior)))
+    s.add(Sphere((0., 1.5, 1.), 1., sdl_material(transparency=0.6, reflectiveness=0.5)))
     s.add(Sphere((-2.5, 1.0, 0.), 0.8, sdl_material(Texture.solid((255, 40, 40)), reflectiveness=0.4)))
     s.add(Aabb((2.5, 0.8, 0.5), (0.7, 0.7, 0.7), sdl_material(Texture.solid((90, 120, 255)), transparency=0.5, ior=1.)))
     s.add(Aabb((-1., 3.5, -2.), (0.4, 0.1, 0.4), sdl_material(Texture.solid((255, 255, 200)), emissivity=1.)))
