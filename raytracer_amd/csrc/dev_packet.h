@@ -181,7 +181,8 @@ __device__ bool packet_traverse(const DMesh& Mg, const Ray& ray, bool active, do
 #ifndef RT_QFLUSH
 #define RT_QFLUSH 48   /* pairs waiting at which the walk stops for a round (a little short of a full round: the rays found blocked leave the packet sooner, 4 % fewer node steps) */
 #endif
-#define RT_QCAP 320                       /* 63 pairs left over + the up to 4 x 64 one node step can add */
+#define RT_QCAP 304                       /* fewer than RT_QFLUSH pairs left over + the up to 4 x 64 that one node step, or one round of node tests, can add */
+static_assert(RT_QCAP >= RT_QFLUSH + 255, "the pair queue must take one step's pairs on top of what a round leaves waiting");
 #define RT_PACKET_MAX_PRIMS (1u << 26)    /* a pair is (leaf's first triangle << 6) | lane in one word */
 #define RT_PWAVES (RT_BLOCK_DIM / 64)
 __shared__ double rt_qray[RT_PWAVES * 6 * 64];                // [wave][o.x o.y o.z d.x d.y d.z][lane]
@@ -811,7 +812,9 @@ __device__ bool cast_closest_packet(const DScene* Sp, const Ray& ray, bool activ
 // the last walk nothing of the ray is needed any more, so it does not have to survive the walk in registers).
 // With a budget, a wave whose mesh walk runs long gives up: `unresolved` then holds the lanes whose cast is still
 // open, to be cast again piecewise.
-template <bool BUDGET>
+// RECIP = false: the caller vouches that no cube is on the linear list and that the scene has no object tree; `ray`
+// then needs its origin and direction only.
+template <bool BUDGET, bool RECIP = true>
 __device__ bool cast_any_packet(const DScene* Sp, const Ray& ray, bool active, bool limited, double dist, Visits& vc,
                                 uint32_t budget, unsigned long long& unresolved) {
     const DScene& S = *Sp;
@@ -827,16 +830,17 @@ __device__ bool cast_any_packet(const DScene* Sp, const Ray& ray, bool active, b
             double near; bool hit;
             if (kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
             else if (kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)payload, ray, near);
-            else hit = box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
+            else if (RECIP) hit = box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
+            else hit = false;
             if (hit && (!limited || near <= dist)) blocked = true;
         }
     }
     // the object tree: as a packet too, but for rays whose direction is not of unit length (they do not cull, tlas_culls)
-    if (S.n_tlas && active && !blocked && !tlas_culls(ray)) blocked = tlas_any(S, ray, limited, dist);
+    if (RECIP && S.n_tlas && active && !blocked && !tlas_culls(ray)) blocked = tlas_any(S, ray, limited, dist);
     if (!__ballot(active && !blocked)) return blocked;
     const bool open = active && !blocked;   // the lanes whose cast the object tree and the meshes decide
     park_rays(ray, open, limited ? dist : INFINITY);
-    if (S.n_tlas) {
+    if (RECIP && S.n_tlas) {
         unsigned long long unres = 0;
         packet_deferred<BUDGET, false, true>(&Sp->tlas_mesh, vc, budget, unres, Sp);
         const unsigned long long still = __ballot(open && !parked_blocked());

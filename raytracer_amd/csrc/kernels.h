@@ -297,6 +297,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_long_trace(const DScene* Sp, DLeve
 
 // The shadow ray of lit hit `hh` towards light `Lt` (sun.rs:87-94, point.rs:68-76,89-99).  cast = 0: the light casts
 // no ray here (sun with shadows off; point light beyond max_distance: LightShading::default()).
+// FULL = false: origin and direction only, for a cast that never reads 1/direction (three f64 divisions, ray.rs:17-23).
+template <bool FULL = true>
 DEV Ray shadow_ray(const RT_GLOBAL DLight* Lt, const double* hs, uint32_t stride, uint32_t hh, uint32_t& cast, bool& limited, double& dist) {
     const D3 vnear = d3(hs[hh], hs[(size_t)stride + hh], hs[2 * (size_t)stride + hh]);
     const D3 so = d3(hs[3 * (size_t)stride + hh], hs[4 * (size_t)stride + hh], hs[5 * (size_t)stride + hh]);
@@ -313,7 +315,10 @@ DEV Ray shadow_ray(const RT_GLOBAL DLight* Lt, const double* hs, uint32_t stride
         dir = lvec / dist;
         limited = true;
     }
-    return ray_new(so, dir);
+    if (FULL) return ray_new(so, dir);
+    Ray r = {};
+    r.o = so; r.d = dir;
+    return r;
 }
 
 // One thread per (lit hit, light): the light's shadow cast.  Lanes of a wave
@@ -325,7 +330,9 @@ DEV Ray shadow_ray(const RT_GLOBAL DLight* Lt, const double* hs, uint32_t stride
 #ifndef RT_SHADOW_ATTR
 #define RT_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(7, 7)))
 #endif
-template <bool COUNT, bool BUDGET>
+// RECIP = false: no cube stands outside the object tree and there is no object tree, so nothing in the cast reads
+// 1/direction (aabb.rs:18-67 is its only reader here) and the ray comes without it.
+template <bool COUNT, bool BUDGET, bool RECIP = true>
 __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
                                                                                                           DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
     const uint32_t h = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -337,11 +344,11 @@ __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene
     if (__ballot(have)) {   // the grid is sized for the worst case: most waves past the hit count have nothing to do
         const uint32_t hh = have ? h : 0;
         bool limited; double dist;
-        const Ray ray = shadow_ray(gptr(S.lights) + li, hs, stride, hh, cast, limited, dist);
+        const Ray ray = shadow_ray<RECIP>(gptr(S.lights) + li, hs, stride, hh, cast, limited, dist);
         if (!have) cast = 0;
         // the wave's shadow rays leave neighbouring hit points towards one light: walked as a packet
         unsigned long long unresolved = 0;
-        const bool blocked = cast_any_packet<BUDGET>(Sp, ray, cast != 0, limited, dist, vc, lp.budget_wave, unresolved);
+        const bool blocked = cast_any_packet<BUDGET, RECIP>(Sp, ray, cast != 0, limited, dist, vc, lp.budget_wave, unresolved);
         if (cast) occ[(size_t)li * stride + hitlist[hh]] = blocked ? 1 : 0;
         if (BUDGET && unresolved) {
             // the wave gave up: its open rays go on the long-ray list (k_long_shadow sets their byte when blocked)

@@ -116,6 +116,7 @@ struct rt_ctx {
     hipStream_t side[RT_SIDE_STREAMS] = {nullptr, nullptr, nullptr, nullptr};   // shadow + lighting of level d runs on side[d % N]
     LongParams long_params = {0u, 256u};              // walk budgets (inner nodes per lane / per wave) before a ray goes on the long-ray list; 0 = off
     bool any_need_far = false;                        // some mesh's material needs Hit::far (transparency with ior == 1)
+    bool shadow_reads_reciprocal = true;              // the shadow packets meet a cube or the object tree: their rays carry 1/direction (k_shadow<.., RECIP>)
     bool any_mesh_refracts = false;                   // some mesh has a refracting material (transparency with ior != 1): k_spawn needs the mesh walk
     uint32_t packet_depth = 0;                        // levels 0..packet_depth trace their rays as wave packets
     uint32_t defer_objects_below = 0;                 // scenes without meshes: levels below this one walk the object tree as deferred packets (the others lane by lane)
@@ -868,8 +869,15 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
             } else {
                 auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc, long_shadow, lp); };
                 const bool cnt = (c->count_visits & 2) != 0;
-                if (lp.budget_wave) { if (cnt) launch(k_shadow<true, true>); else launch(k_shadow<false, true>); }
-                else { main_variant = true; if (cnt) launch(k_shadow<true, false>); else launch(k_shadow<false, false>); }
+                const bool rcp = c->shadow_reads_reciprocal;
+                if (lp.budget_wave) {
+                    if (cnt) launch(k_shadow<true, true>);
+                    else if (rcp) launch(k_shadow<false, true>); else launch(k_shadow<false, true, false>);
+                } else {
+                    main_variant = true;
+                    if (cnt) launch(k_shadow<true, false>);
+                    else if (rcp) launch(k_shadow<false, false>); else launch(k_shadow<false, false, false>);
+                }
             }
         }
         HIP_TRY(c, hipEventRecord(W.ev[LW_SK], side));
@@ -1285,6 +1293,8 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
         std::vector<uint32_t> linear;
         for (uint32_t i = 0; i < d->n_objects; i++) if (objs[i].kind == RT_OBJ_MESH || !(objs[i].need_far & RT_IN_TLAS)) linear.push_back(i);
         H.n_linear = (uint32_t)linear.size();
+        c->shadow_reads_reciprocal = H.n_tlas != 0;
+        for (uint32_t i : linear) if (objs[i].kind == RT_OBJ_BOX) c->shadow_reads_reciprocal = true;
         if ((rc = upload(c, linear.data(), linear.size(), &H.linear)) != RT_OK) return rc;
     }
 
