@@ -440,7 +440,9 @@ DEV void light_shading(const DLight& Lt, const Ray& ray, const Hit& hit, bool sh
 // kernel (no LDS, a third of the registers), which matters because it sits on the frame's critical path beside a
 // chip full of shadow waves.
 template <bool COUNT, bool MESHREF>
-__global__ __launch_bounds__(RT_BLOCK) void k_spawn(const DScene* Sp, DLevel L, DLevel N, uint32_t n, const unsigned long long* n_dev, uint32_t depth,
+// (the light variant is asked to fit 6 waves per SIMD, 78 registers without spills against 94 when left alone: the
+// kernel streams hit records and waits on memory; the variant with the mesh walk is left alone)
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(MESHREF ? 1 : 6, 8))) void k_spawn(const DScene* Sp, DLevel L, DLevel N, uint32_t n, const unsigned long long* n_dev, uint32_t depth,
                                                     uint32_t next_cap, DCounters* C, DLevelCounts* LC, uint32_t* ids_out, ShardMap map) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     n = level_size(n, n_dev);
@@ -560,7 +562,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_count_children(const DScene* Sp, D
 
 // The lit colour of every hit that k_spawn left pending (scene.rs:102-122), from the shadow casts' results.  A hit
 // without children is final here; the others keep the colour for k_resolve.
-__global__ __launch_bounds__(RT_BLOCK) void k_light(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, const uint8_t* occ, uint32_t stride) {
+// (64 registers, 8 waves per SIMD, no spills; 80 when left alone)
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_light(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, const uint8_t* occ, uint32_t stride) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= level_size(n, n_dev)) return;
     const uint32_t bf = L.base_flags[i];
