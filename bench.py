@@ -17,7 +17,7 @@ renders them strictly one after the other.  A set of launches covers --batch B c
 launches as large as a whole frame's.  The line also carries the one-frame-at-a-time figure (`ms_per_frame_alone`) and, on one GPU, the time per
 frame through rt_render, host pixels included (`ms_per_frame_end_to_end`).
 
-Roofline of the dominant kernel (the budget-free shadow packet kernel, k_shadow<false, false>): its launches are timed
+Roofline of the dominant kernel (the budget-free shadow packet kernel, k_shadow<false, false, false>): its launches are timed
 alone (a context whose kernels run one after the other, HIP events around the kernel on its own stream); numerators
 are work the kernel really does -- BVH bytes its walks fetch (instrumented variant), HBM-side bytes and VALU-busy
 cycles from the rocprofv3 counter passes kept under profiles/ -- and `bound` is the roof it comes closest to.
@@ -264,7 +264,7 @@ def main():
         pipe.close()
         pipe = None
         # (2) the dominant kernel alone: a context whose kernels run one after the other on one stream, so that the
-        #     HIP events around k_shadow<false, false> (on that stream) bracket nothing else
+        #     HIP events around k_shadow<false, false, false> (on that stream) bracket nothing else
         os.environ["RTGPU_SERIAL"] = "1"
         sctx = ra.Context(local_rank)
         sctx.upload(scene)
@@ -347,7 +347,7 @@ def main():
                     fr["inputs_error"] = repr(e)
             hw = [k for k in ("valu", "hbm") if k in fr] or ["bvh_bytes_touched"]   # (no counter file: the side figure stands in)
             bound = max(hw, key=lambda k: fr[k]["frac"])
-            roofline = {"bound": bound, "kernel": "k_shadow<false, false>", "achieved": fr[bound]["achieved"], "peak": fr[bound]["peak"],
+            roofline = {"bound": bound, "kernel": "k_shadow<false, false, false>", "achieved": fr[bound]["achieved"], "peak": fr[bound]["peak"],
                         "unit": fr[bound]["unit"], "frac": fr[bound]["frac"], "traffic": traffic,
                         "avg_launch_ms": serial["k_shadow_main_avg_launch_ms"], "launches_per_frame": n_l,
                         "share_of_frame_kernel_time": serial["k_shadow_main_avg_launch_ms"] * n_l / serial["ms_per_frame_kernels"],

@@ -10,7 +10,7 @@ chip); hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, FETCH_SIZE d
 import collections, csv, glob, json, sys
 
 pmc, traffic = sys.argv[1], sys.argv[2]
-KERNEL = "k_shadow<false, false>"
+KERNEL = "k_shadow<false, false, false>"   # (not counted, no budget, rays without 1/direction: the variant config 4 runs)
 agg = collections.defaultdict(float)
 launches = collections.defaultdict(int)
 for f in glob.glob(f"gpurun_out/{pmc}/p*/*counter_collection.csv") + glob.glob(f"gpurun_out/{traffic}/*/**/*counter_collection.csv", recursive=True):
