@@ -26,7 +26,28 @@ DEV D3 operator-(D3 a) { return d3(-a.x, -a.y, -a.z); }
 DEV double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                       // vector.rs:60-62
 DEV D3 cross(D3 a, D3 b) { return d3(a.y * b.z - a.z * b.y, -a.x * b.z + a.z * b.x, a.x * b.y - a.y * b.x); }  // :65-71
 DEV double magnitude(D3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }                 // :74-76
-DEV D3 normalize(D3 a) { return a / magnitude(a); }                                            // :79-81
+// a / s for s = magnitude(a) (vector.rs:192-202: three divisions by one divisor).  The compiler's f64 division is
+// v_div_scale on both operands, v_rcp_f64 and two Newton steps on the reciprocal, q0 = n * r, rem = fma(-d, q0, n),
+// q = fma(rem, r, q0), v_div_fixup.  Scale and fixup change nothing while divisor and quotient stay clear of the ends of
+// the exponent range and no operand is 0, inf or NaN, and the reciprocal's part depends on the divisor alone: here it is
+// worked out once for the three numerators, by the same operations in the same order, so the quotients are the same
+// bits (14 instructions instead of 39; tools/div_check.hip compares the two over the exponent range).  Outside that
+// range -- a component below 2^-200, zeros included, or a magnitude outside [2^-200, 2^200] -- the plain divisions run.
+DEV D3 div_by_norm(D3 a, double s) {
+    const double LO = 0x1p-200, HI = 0x1p200;
+    if (s >= LO && s <= HI && fabs(a.x) >= LO && fabs(a.y) >= LO && fabs(a.z) >= LO) {
+        double r = __builtin_amdgcn_rcp(s);
+        r = fma(r, fma(-s, r, 1.0), r);
+        r = fma(r, fma(-s, r, 1.0), r);
+        double qx = a.x * r, qy = a.y * r, qz = a.z * r;
+        qx = fma(fma(-s, qx, a.x), r, qx);
+        qy = fma(fma(-s, qy, a.y), r, qy);
+        qz = fma(fma(-s, qz, a.z), r, qz);
+        return d3(qx, qy, qz);
+    }
+    return a / s;
+}
+DEV D3 normalize(D3 a) { return div_by_norm(a, magnitude(a)); }                                // :79-81
 template <typename P> DEV D3 ld3(P p) { return d3(p[0], p[1], p[2]); }
 
 // Rust f64::signum: NaN -> NaN, otherwise +-1 with the sign of x (signum(+-0) = +-1)

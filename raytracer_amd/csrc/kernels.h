@@ -312,7 +312,7 @@ DEV Ray shadow_ray(const RT_GLOBAL DLight* Lt, const double* hs, uint32_t stride
         D3 lvec = lv - vnear;
         dist = magnitude(lvec);
         cast = dist > Lt->max_distance ? 0u : 1u;
-        dir = lvec / dist;
+        dir = div_by_norm(lvec, dist);
         limited = true;
     }
     if (FULL) return ray_new(so, dir);
@@ -423,7 +423,7 @@ DEV void light_shading(const DLight& Lt, const Ray& ray, const Hit& hit, bool sh
     D3 lvec = ld3(Lt.v) - hit.vnear;
     double dist = magnitude(lvec);
     if (dist > Lt.max_distance) { diffuse = 0.; specular = 0.; intensity = 0.; return; }   // LightShading::default()
-    lvec = lvec / dist;
+    lvec = div_by_norm(lvec, dist);
     diffuse = clampd(dot(hit.normal, lvec), 0., FMAX);
     D3 halfway = normalize(lvec - ray.d);
     specular = rt_powi(clampd(dot(hit.normal, halfway), 0., FMAX), Lt.specular_power);
