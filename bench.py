@@ -13,8 +13,8 @@ timed region; the frame stays in HBM.  A ray is one Scene::cast_ray_once call of
 The K timed frames are a sequence (the reference's --sequence workload): --frames-in-flight F sets of launches (default
 3 on one GPU, 2 when the frame is sharded) are in flight per GPU, each frame complete and delivered in order; F = 1
 renders them strictly one after the other.  A set of launches covers --batch B consecutive frames (rt_render_shard_batch):
-2 whole frames on one GPU, and this rank's shard of N frames when the frame is sharded over N GPUs, which keeps the
-launches as large as a whole frame's.  The line also carries the one-frame-at-a-time figure (`ms_per_frame_alone`) and, on one GPU, the time per
+2 whole frames on one GPU; when the frame is sharded over N GPUs, this rank's shard of half of the K frames (at most 5 N),
+which keeps the launches at least as large as a whole frame's and the run down to one fill and one drain of the chip.  The line also carries the one-frame-at-a-time figure (`ms_per_frame_alone`) and, on one GPU, the time per
 frame through rt_render, host pixels included (`ms_per_frame_end_to_end`).
 
 Roofline of the dominant kernel (the budget-free shadow packet kernel, k_shadow<false, false, false>): its launches are timed
@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--lights", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--frames-in-flight", type=int, default=None)
-    ap.add_argument("--batch", type=int, default=None, help="frames per set of launches (default: 1 on one GPU, N on N GPUs)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per set of launches (default: 2 on one GPU; half of the steps, at most 5 N, on N GPUs)")
     args = ap.parse_args()
 
     import torch
@@ -188,7 +188,10 @@ def main():
     small = vw * vh <= 3840 * 2160          # (an 8K frame's wavefront levels take tens of GB per frame in flight)
     if args.batch is None:
         # two whole frames per set of launches, three sets in flight: 3-4 % more frames per second than four single frames
-        args.batch = (2 if small else 1) if world == 1 else min(world, 8)
+        # sharded: the K frames as two sets of launches side by side (one fill and one drain of the chip for the whole
+        # run: a 1/8 shard of 20 frames is 20 ms of work, and every further set would add its own tail of small deep
+        # levels), each at most five whole frames' worth of rays
+        args.batch = (2 if small else 1) if world == 1 else max(1, min((args.steps + 1) // 2, 5 * world))
     if args.frames_in_flight is None:
         args.frames_in_flight = (3 if args.batch > 1 else 4) if world == 1 and small else 2
     depth, batch = max(1, args.frames_in_flight), max(1, args.batch)

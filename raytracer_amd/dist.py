@@ -202,9 +202,12 @@ class FramePipeline:
         Returns the list of RtStats of this rank, one per set of launches."""
         B = self.batch
         n_jobs = (n_frames + B - 1) // B
+        # sets of launches of as equal a size as possible (20 frames in sets of at most 8: 7 + 7 + 6, not 8 + 8 + 4): a
+        # short last set would render alone, with nothing to fill the chip beside it
+        first = [j * (n_frames // n_jobs) + min(j, n_frames % n_jobs) for j in range(n_jobs + 1)] if n_jobs else [0]
 
         def job(j):
-            lo, hi = j * B, min((j + 1) * B, n_frames)
+            lo, hi = first[j], first[j + 1]
             if camera_of is not None:
                 return (j, self.ctxs[j % self.depth].camera_array([camera_of(f) for f in range(lo, hi)]))
             return (j, None if B == 1 else hi - lo)
@@ -218,7 +221,7 @@ class FramePipeline:
             if isinstance(st, Exception):
                 raise st
             r = self.renderers[k]
-            lo, hi = j * B, min((j + 1) * B, n_frames)
+            lo, hi = first[j], first[j + 1]
             st.frames = hi - lo
             frames = gather_frame(r.local, r.vw, r.vh, self.rank, self.world, r.detile)
             if on_frame is not None:

@@ -188,7 +188,10 @@ def _batch_worker(rank, world, port, vw, vh, n_frames, batch, out_path):
         stats = pipe.run(n_frames, on_frame, camera_of=_path_camera)
         pipe.close()
         assert len(stats) == -(-n_frames // batch) and len(covered) == n_frames
-        assert covered[-1] == (n_frames % batch or batch)
+        # sets of as equal a size as possible: 7 frames in sets of at most 3 are 3 + 2 + 2
+        n_sets = -(-n_frames // batch)
+        sizes = [n_frames // n_sets + (1 if j < n_frames % n_sets else 0) for j in range(n_sets)]
+        assert covered == [b for b in sizes for _ in range(b)] and max(sizes) <= batch
         if rank == 0:
             np.save(out_path, np.stack(frames))
     finally:
@@ -196,7 +199,7 @@ def _batch_worker(rank, world, port, vw, vh, n_frames, batch, out_path):
 
 
 def test_gloo_batched_pipeline_delivers_every_frame_of_a_camera_path(tmp_path):
-    """batches of 3 frames per set of launches, two batches in flight, world size 2, a last batch of one frame"""
+    """at most 3 frames per set of launches (7 frames: 3 + 2 + 2), two sets in flight, world size 2"""
     sys.path.insert(0, ROOT)
     import oracle
     from raytracer_amd import scenes
