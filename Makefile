@@ -1,4 +1,4 @@
-# Builds the three shared libraries in-tree:
+# Builds the three shared libraries (and one self-check program, raytracer_amd/div_check.bin) in-tree:
 #   raytracer_amd/librtgpu.so   HIP render path behind include/rtgpu.h (gfx950)
 #   raytracer_amd/librthost.so  C++ mirror of the reference's Scene API (host only)
 #   oracle/liboracle.so         CPU checker (test infrastructure, never linked by the two above)
@@ -14,7 +14,7 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off
 HOST_SRC := raytracer_amd/host/mesh.cpp raytracer_amd/host/scene.cpp raytracer_amd/host/png.cpp raytracer_amd/host/jpeg.cpp raytracer_amd/host/sdl.cpp raytracer_amd/host/capi.cpp
 HOST_HDR := raytracer_amd/host/scene.hpp raytracer_amd/host/sdl.hpp raytracer_amd/host/rmath.hpp include/rtgpu.h
 
-all: raytracer_amd/librtgpu.so raytracer_amd/librthost.so oracle/liboracle.so
+all: raytracer_amd/librtgpu.so raytracer_amd/librthost.so oracle/liboracle.so raytracer_amd/div_check.bin
 
 # -ffp-contract=off: the reference never fuses a multiply-add; neither may the device code
 # two translation units (the tree builder pulls in the rocPRIM sort and compiles slowly; no device code calls across them)
@@ -32,10 +32,14 @@ raytracer_amd/librtgpu.so: build/obj/rtgpu.o build/obj/bvh_build.o
 raytracer_amd/librthost.so: $(HOST_SRC) $(HOST_HDR) raytracer_amd/librtgpu.so
 	$(CXX) -O2 -std=c++17 -fPIC -shared -pthread -ffp-contract=off -o $@ $(HOST_SRC) -Lraytracer_amd -lrtgpu -lz -Wl,-rpath,'$$ORIGIN'
 
+# a self-check of one device function (dev_rt.h div_by_norm against the plain divisions, bit for bit); the GPU tests run it
+raytracer_amd/div_check.bin: tools/div_check.hip raytracer_amd/csrc/dev_rt.h raytracer_amd/csrc/dev_types.h
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -Iinclude -o $@ tools/div_check.hip
+
 oracle/liboracle.so: oracle/oracle.cpp oracle/oracle.h include/rtgpu.h
 	$(CXX) -O2 -std=c++17 -fPIC -shared -pthread -ffp-contract=off -fno-fast-math -o $@ oracle/oracle.cpp
 
 clean:
-	rm -f raytracer_amd/librtgpu.so raytracer_amd/librthost.so oracle/liboracle.so
+	rm -f raytracer_amd/librtgpu.so raytracer_amd/librthost.so oracle/liboracle.so raytracer_amd/div_check.bin
 
 .PHONY: all clean

@@ -769,3 +769,20 @@ def test_refit_after_the_vertices_moved():
         assert id_match(got_ids, want_ids) >= ID_BAR and image_metrics(got, want)["exact"] >= 0.9999
         o_rgb, o_ids, _, _ = oracle.render(fresh, 0)
         assert_parity(got, got_ids, o_rgb, o_ids, exact_floor=0.9999)
+
+
+def test_shared_reciprocal_divisions_equal_the_plain_ones():
+    """dev_rt.h div_by_norm (a vector over its own magnitude: three f64 divisions through one refined reciprocal) against
+    the compiler's own divisions, bit for bit: 3.7e9 random vectors whose components' exponents sweep +-2 ... +-1000, with
+    and without exact zeros (raytracer_amd/div_check.bin, built by `make all` from tools/div_check.hip and the same
+    header as the library).  vector.rs:192-202 divides component by component; the reference's quotients are what the
+    plain divisions give."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(ra.__file__)), "div_check.bin")
+    assert os.path.exists(exe), "raytracer_amd/div_check.bin is built by `make all`"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    lines = [l for l in out.stdout.splitlines() if "differ" in l]
+    assert out.returncode == 0 and len(lines) == 14, out.stdout + out.stderr
+    assert all(l.rstrip().endswith(" 0 differ") for l in lines), out.stdout
+    # the fast path is what ran: every vector of the narrow sweeps, almost none of the widest
+    assert "100.0 % through the shared reciprocal" in lines[0] and " 0.8 % through the shared reciprocal" in lines[6]

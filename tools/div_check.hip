@@ -1,7 +1,7 @@
 // Compares div_by_norm (raytracer_amd/csrc/dev_rt.h: three divisions by one magnitude through one shared reciprocal)
 // with the compiler's own f64 divisions, bit for bit, over vectors whose components' exponents sweep a chosen range.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -Iinclude -o exp/div_check.bin tools/div_check.hip
-//   exp/div_check.bin            (on the GPU box)
+//   make raytracer_amd/div_check.bin     (hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off, as the library)
+//   raytracer_amd/div_check.bin          (on the GPU box; status 1 if any quotient differs)
 #include <cstdio>
 #include <cstdint>
 #include <hip/hip_runtime.h>
