@@ -191,7 +191,7 @@ def main():
         # sharded: the K frames as two sets of launches side by side (one fill and one drain of the chip for the whole
         # run: a 1/8 shard of 20 frames is 20 ms of work, and every further set would add its own tail of small deep
         # levels), each at most five whole frames' worth of rays
-        args.batch = (2 if small else 1) if world == 1 else max(1, min((args.steps + 1) // 2, 5 * world))
+        args.batch = (2 if small else 1) if world == 1 else max(1, min((args.steps + 1) // 2, 5 * world, 64))   # (64: RT_BATCH_MAX)
     if args.frames_in_flight is None:
         args.frames_in_flight = (3 if args.batch > 1 else 4) if world == 1 and small else 2
     depth, batch = max(1, args.frames_in_flight), max(1, args.batch)
