@@ -763,7 +763,9 @@ __device__ bool packet_closest_objects(const DScene* Sp, const Ray& ray, bool ac
 // of the kernel (it costs registers, hence waves per SIMD, even when it never runs).
 // DEFER: the meshes are walked by packet_closest_deferred (triangle tests and thin ends of the walk set aside)
 // instead of packet_traverse.
-template <bool FAR, bool DEFER = false>
+// RECIP = false: the caller vouches that no cube is on the linear list and that the scene has no object tree; `ray`
+// then needs its origin and direction only.
+template <bool FAR, bool DEFER = false, bool RECIP = true>
 __device__ bool cast_closest_packet(const DScene* Sp, const Ray& ray, bool active, Closest& c, Visits& vc) {
     const DScene& S = *Sp;
     c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
@@ -789,11 +791,11 @@ __device__ bool cast_closest_packet(const DScene* Sp, const Ray& ray, bool activ
         if (active) {
             if (kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
             else if (kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)payload, ray, near);
-            else hit = box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
+            else if (RECIP) hit = box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
         }
         if (hit && (!any || near < c.t)) { c.obj = oi; c.rank = RT_NONE; c.t = near; any = true; }
     }
-    if (S.n_tlas) {
+    if (RECIP && S.n_tlas) {
         if (DEFER) {
             // rays whose direction is not of unit length do not cull (tlas_culls): lane by lane, every object
             const bool culls = tlas_culls(ray);

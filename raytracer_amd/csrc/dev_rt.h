@@ -941,14 +941,15 @@ __device__ bool cast_any_analytic(const DScene& S, const Ray& ray, bool limited,
 }
 
 // Rebuilds the full Hit of the closest object from the trace record
-template <bool MESHES = true>
+// BOXES = false: the caller vouches that the scene has no cube (and `ray` may come without 1/direction)
+template <bool MESHES = true, bool BOXES = true>
 __device__ void closest_hit_fill(const DScene& S, const Ray& ray, uint32_t obj, uint32_t rank, double t, double t2, float u, float v, Hit& h) {
     const RT_GLOBAL DObject* op = gptr(S.objects) + obj;
     const uint32_t kind = op->kind, payload = op->payload;
     if (MESHES && kind == 3) mesh_hit_fill(S.meshes[payload], ray, rank, t, t2, u, v, h);
     else if (kind == 0) sphere_intersect(gptr(S.spheres) + 4 * (size_t)payload, ray, h);
     else if (kind == 1) plane_intersect(gptr(S.planes) + 8 * (size_t)payload, ray, h);
-    else box_intersect(ld3(gptr(S.boxes) + 6 * (size_t)payload), ld3(gptr(S.boxes) + 6 * (size_t)payload + 3), ray, h);
+    else if (BOXES) box_intersect(ld3(gptr(S.boxes) + 6 * (size_t)payload), ld3(gptr(S.boxes) + 6 * (size_t)payload + 3), ray, h);
 }
 
 // ---------------------------------------------------------------- material.rs:119-141

@@ -54,8 +54,15 @@ DEV bool slot_pixel(const ShardMap& m, int32_t vw, int32_t vh, uint32_t slot, in
     return x < vw && y < vh;
 }
 
+// FULL = false: origin and direction only -- for kernels of scenes in which nothing reads 1/direction (three f64
+// divisions, ray.rs:17-23; its readers are the cube test of aabb.rs:18-67 and the lane-by-lane box walks)
+template <bool FULL = true>
 DEV Ray load_ray(const DLevel& L, uint32_t i) {
-    return ray_new(d3(L.ro[0][i], L.ro[1][i], L.ro[2][i]), d3(L.rd[0][i], L.rd[1][i], L.rd[2][i]));
+    const D3 o = d3(L.ro[0][i], L.ro[1][i], L.ro[2][i]), d = d3(L.rd[0][i], L.rd[1][i], L.rd[2][i]);
+    if (FULL) return ray_new(o, d);
+    Ray r = {};
+    r.o = o; r.d = d;
+    return r;
 }
 DEV void store_ray(const DLevel& L, uint32_t i, D3 o, D3 d) {
     L.ro[0][i] = o.x; L.ro[1][i] = o.y; L.ro[2][i] = o.z;
@@ -155,7 +162,7 @@ struct LongParams { uint32_t budget_lane, budget_wave; };
 // and k_light to read back in coalesced loads instead of each fetching the triangle's indices, normals and texture
 // coordinates again), and the entry of the shadow work list (hit point and the offset origin vnear + normal * EPSILON
 // of sun.rs:88, point.rs:90) when the hit will be lit
-template <bool MESHES = true>
+template <bool MESHES = true, bool BOXES = true>
 DEV void trace_finish(const DScene& S, DLevel& L, uint32_t i, bool active, const Ray& ray, bool hit, const Closest& c,
                       uint32_t* hitlist, double* hs, uint32_t stride, DLevelCounts* LC) {
     bool lit = false;
@@ -163,7 +170,7 @@ DEV void trace_finish(const DScene& S, DLevel& L, uint32_t i, bool active, const
     if (active) L.hit_obj[i] = c.obj;
     if (active && hit) {
         Hit h;
-        closest_hit_fill<MESHES>(S, ray, c.obj, c.rank, c.t, c.t2, c.u, c.v, h);
+        closest_hit_fill<MESHES, BOXES>(S, ray, c.obj, c.rank, c.t, c.t2, c.u, c.v, h);
         L.hit_prim[i] = h.prim;
         L.hit_t[i] = h.near; L.hit_t2[i] = h.far; L.hit_u[i] = h.u; L.hit_v[i] = h.v;
         L.nrm[0][i] = h.normal.x; L.nrm[1][i] = h.normal.y; L.nrm[2][i] = h.normal.z;
@@ -208,7 +215,9 @@ DEV void load_hit(const DLevel& L, uint32_t i, const Ray& ray, Hit& h) {
 #define RT_TRACE_PACKET_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
 #endif
 // MESHES = false: a scene of analytic objects only (lane by lane, no budget): the mesh walks stay out of the kernel.
-template <bool COUNT, bool PACKET, bool BUDGET, bool FAR, bool MESHES, bool DEFER = false>
+// RECIP = false (deferred packets only): the scene has neither a cube outside the object tree nor an object tree, and
+// the rays come without 1/direction: three divisions less per ray, and six registers less to carry through the walk.
+template <bool COUNT, bool PACKET, bool BUDGET, bool FAR, bool MESHES, bool DEFER = false, bool RECIP = true>
 DEV void trace_body(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, uint32_t* hitlist, double* hs, uint32_t stride,
                     DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -218,12 +227,13 @@ DEV void trace_body(const DScene* Sp, DLevel L, uint32_t n, const unsigned long 
     Visits vc; vc.nodes = 0; vc.tris = 0; vc.wnodes = 0; vc.wtris = 0; vc.units = 0;
     bool active = i < n && L.hit_obj[i] != RT_INACTIVE;
     const uint32_t ii = i < n ? i : 0;
-    Ray ray = load_ray(L, ii);
+    static_assert(RECIP || (DEFER && !FAR), "only the deferred packets can do without 1/direction");
+    Ray ray = load_ray<RECIP>(L, ii);
     Closest c; c.obj = RT_NONE; c.rank = RT_NONE; c.t = 0.; c.t2 = 0.; c.u = 0.f; c.v = 0.f;
     bool hit = false;
     if (PACKET) {
         // the wave's rays are coherent (primary rays of an 8x8 pixel block) and walk the BVH together
-        hit = cast_closest_packet<FAR, DEFER>(Sp, ray, active, c, vc);
+        hit = cast_closest_packet<FAR, DEFER, RECIP>(Sp, ray, active, c, vc);
     } else if (active && !BUDGET) {
         hit = MESHES ? cast_closest<FAR>(S, ray, c, vc) : cast_closest_analytic(S, ray, c);
     } else if (active) {
@@ -234,7 +244,7 @@ DEV void trace_body(const DScene* Sp, DLevel L, uint32_t n, const unsigned long 
             active = false; hit = false;
         }
     }
-    trace_finish<MESHES>(S, L, i, active, ray, hit, c, hitlist, hs, stride, LC);
+    trace_finish<MESHES, RECIP>(S, L, i, active, ray, hit, c, hitlist, hs, stride, LC);
     if (COUNT) {
         DShard* sh = my_shard(C);
         if (PACKET) { if (lane_id() == 0) atomicMax(&sh->max_wave_steps, (unsigned long long)(vc.wnodes + vc.wtris)); }
@@ -258,10 +268,10 @@ __global__ __launch_bounds__(RT_BLOCK) RT_TRACE_PACKET_ATTR void k_trace_packet(
 #ifndef RT_TRACE_DEFER_ATTR
 #define RT_TRACE_DEFER_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
 #endif
-template <bool COUNT>
+template <bool COUNT, bool RECIP = true>
 __global__ __launch_bounds__(RT_BLOCK) RT_TRACE_DEFER_ATTR void k_trace_deferred(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, uint32_t* hitlist, double* hs, uint32_t stride,
                                                     DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
-    trace_body<COUNT, true, false, false, true, true>(Sp, L, n, n_dev, hitlist, hs, stride, C, LC, longlist, lp);
+    trace_body<COUNT, true, false, false, true, true, RECIP>(Sp, L, n, n_dev, hitlist, hs, stride, C, LC, longlist, lp);
 }
 
 // The listed long rays of a level, RT_SEGS lanes each: lane k walks piece k of the ray through every mesh, the

@@ -116,7 +116,7 @@ struct rt_ctx {
     hipStream_t side[RT_SIDE_STREAMS] = {nullptr, nullptr, nullptr, nullptr};   // shadow + lighting of level d runs on side[d % N]
     LongParams long_params = {0u, 256u};              // walk budgets (inner nodes per lane / per wave) before a ray goes on the long-ray list; 0 = off
     bool any_need_far = false;                        // some mesh's material needs Hit::far (transparency with ior == 1)
-    bool shadow_reads_reciprocal = true;              // the shadow packets meet a cube or the object tree: their rays carry 1/direction (k_shadow<.., RECIP>)
+    bool rays_need_reciprocal = true;              // the packets meet a cube or the object tree: their rays carry 1/direction (k_shadow, k_trace_deferred <.., RECIP>)
     bool any_mesh_refracts = false;                   // some mesh has a refracting material (transparency with ior != 1): k_spawn needs the mesh walk
     uint32_t packet_depth = 0;                        // levels 0..packet_depth trace their rays as wave packets
     uint32_t defer_objects_below = 0;                 // scenes without meshes: levels below this one walk the object tree as deferred packets (the others lane by lane)
@@ -817,7 +817,7 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
                 hipLaunchKernelGGL(kern, grid, block, 0, s, c->dscene, c->levels[depth].lv, n, n_dev, hitlist, hs, n, dc, lc, long_trace, lp);
             };
             const bool cnt = (c->count_visits & 1) != 0;
-            if (deferred) { if (cnt) launch(k_trace_deferred<true>); else launch(k_trace_deferred<false>); }
+            if (deferred) { if (cnt) launch(k_trace_deferred<true>); else if (c->rays_need_reciprocal) launch(k_trace_deferred<false>); else launch(k_trace_deferred<false, false>); }
             else if (c->hscene.n_meshes == 0) { if (cnt) launch(k_trace<true, false, false, false, false>); else launch(k_trace<false, false, false, false, false>); }
             else if (depth <= c->packet_depth) {   // (packets pay for mesh walks only)
                 if (c->any_need_far) { if (cnt) launch(k_trace_packet<true, true>); else launch(k_trace_packet<false, true>); }
@@ -869,7 +869,7 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
             } else {
                 auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc, long_shadow, lp); };
                 const bool cnt = (c->count_visits & 2) != 0;
-                const bool rcp = c->shadow_reads_reciprocal;
+                const bool rcp = c->rays_need_reciprocal;
                 if (lp.budget_wave) {
                     if (cnt) launch(k_shadow<true, true>);
                     else if (rcp) launch(k_shadow<false, true>); else launch(k_shadow<false, true, false>);
@@ -1293,8 +1293,8 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
         std::vector<uint32_t> linear;
         for (uint32_t i = 0; i < d->n_objects; i++) if (objs[i].kind == RT_OBJ_MESH || !(objs[i].need_far & RT_IN_TLAS)) linear.push_back(i);
         H.n_linear = (uint32_t)linear.size();
-        c->shadow_reads_reciprocal = H.n_tlas != 0;
-        for (uint32_t i : linear) if (objs[i].kind == RT_OBJ_BOX) c->shadow_reads_reciprocal = true;
+        c->rays_need_reciprocal = H.n_tlas != 0;
+        for (uint32_t i : linear) if (objs[i].kind == RT_OBJ_BOX) c->rays_need_reciprocal = true;
         if ((rc = upload(c, linear.data(), linear.size(), &H.linear)) != RT_OK) return rc;
     }
 
