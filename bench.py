@@ -11,10 +11,10 @@ gathered to rank 0 (RCCL) and scattered into the row-major frame (rt_detile).  T
 timed region; the frame stays in HBM.  A ray is one Scene::cast_ray_once call of the reference.
 
 The K timed frames are a sequence (the reference's --sequence workload): --frames-in-flight F sets of launches (default
-3 on one GPU, 2 when the frame is sharded) are in flight per GPU, each frame complete and delivered in order; F = 1
-renders them strictly one after the other.  A set of launches covers --batch B consecutive frames (rt_render_shard_batch):
-2 whole frames on one GPU; when the frame is sharded over N GPUs, this rank's shard of half of the K frames (at most 5 N),
-which keeps the launches at least as large as a whole frame's and the run down to one fill and one drain of the chip.  The line also carries the one-frame-at-a-time figure (`ms_per_frame_alone`) and, on one GPU, the time per
+2) are in flight per GPU, each frame complete and delivered in order; F = 1 renders them strictly one after the other.
+A set of launches covers --batch B consecutive frames (rt_render_shard_batch): by default half of the K frames -- whole
+frames on one GPU, this rank's shard of them when the frame is sharded over N GPUs -- and at most ten whole frames' worth
+of rays, which keeps the launches large and the run down to one fill and one drain of the chip.  The line also carries the one-frame-at-a-time figure (`ms_per_frame_alone`) and, on one GPU, the time per
 frame through rt_render, host pixels included (`ms_per_frame_end_to_end`).
 
 Roofline of the dominant kernel (the budget-free shadow packet kernel, k_shadow<false, false, false>): its launches are timed
@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--lights", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--frames-in-flight", type=int, default=None)
-    ap.add_argument("--batch", type=int, default=None, help="frames per set of launches (default: 2 on one GPU; half of the steps, at most 5 N, on N GPUs)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per set of launches (default: half of the steps, at most ten whole frames' worth of rays)")
     args = ap.parse_args()
 
     import torch
@@ -182,18 +182,20 @@ def main():
         t_upload[0] = time.perf_counter() - t0
         return c
 
-    # One GPU, whole frame: 4 frames in flight.  A 1/N shard's launches are N times smaller and fill the chip badly
-    # (a 1/8 shard takes 1.7-2.4 ms per frame however many are in flight, against 1.35 for an eighth of a whole frame);
-    # N consecutive frames per set of launches restore their size, and two such sets in flight hide the tails.
+    # A 1/N shard's launches are N times smaller than a whole frame's and fill the chip badly (a 1/8 shard takes 1.5-1.7
+    # ms per frame one frame per set, however many sets are in flight, against 0.91 for an eighth of a whole frame);
+    # several consecutive frames per set of launches restore their size.
     small = vw * vh <= 3840 * 2160          # (an 8K frame's wavefront levels take tens of GB per frame in flight)
     if args.batch is None:
-        # two whole frames per set of launches, three sets in flight: 3-4 % more frames per second than four single frames
-        # sharded: the K frames as two sets of launches side by side (one fill and one drain of the chip for the whole
-        # run: a 1/8 shard of 20 frames is 20 ms of work, and every further set would add its own tail of small deep
-        # levels), each at most five whole frames' worth of rays
-        args.batch = (2 if small else 1) if world == 1 else max(1, min((args.steps + 1) // 2, 5 * world, 64))   # (64: RT_BATCH_MAX)
+        # The K frames as sets of launches of half of them each, two sets side by side: large sets fill the chip through
+        # their deep levels too, and every further set would add its own tail of small launches (one GPU, 20 frames:
+        # 7.09 ms per frame as 2 x 10, 7.18 as sets of 5, 7.24 as sets of 2 three at a time; a 1/8 shard of 20 frames is
+        # 20 ms of work all told).  At most ten whole frames' worth of rays per set (17 GB of wavefront levels at 4K);
+        # an 8K frame's levels take tens of GB each, so those go one frame per set.
+        half = (args.steps + 1) // 2
+        args.batch = max(1, min(half, 10 * world, 64)) if small else (1 if world == 1 else max(1, min(half, world)))   # (64: RT_BATCH_MAX)
     if args.frames_in_flight is None:
-        args.frames_in_flight = (3 if args.batch > 1 else 4) if world == 1 and small else 2
+        args.frames_in_flight = 2
     depth, batch = max(1, args.frames_in_flight), max(1, args.batch)
     pipe = rd.FramePipeline(make_context, rank, world, device, depth=depth, batch=batch)
     t_upload = t_upload[0]

@@ -145,7 +145,9 @@ class ShardedRenderer:
         assert (cameras if isinstance(cameras, int) else len(cameras)) <= self.batch
         return self.ctx.render_shard_batch(self.rank, self.world, cameras, self.local.data_ptr())
 
-    def detile(self, gathered):
+    def detile(self, gathered, n_frames=None):
+        """gathered: (world, n_frames, slots, 3) bytes -- every rank's first n_frames frames of its buffer (default: all
+        `batch` of them)"""
         import torch
         # the gather runs on torch's stream, rt_detile on the context's own: join them here
         if torch.device(self.device).type == "cuda":
@@ -153,7 +155,7 @@ class ShardedRenderer:
         if self.batch == 1:
             self.ctx.detile(gathered.data_ptr(), self.world, self.slots, 3, self.frame.data_ptr())
         else:
-            self.ctx.detile_frames(gathered.data_ptr(), self.world, self.batch, self.slots, 3, self.frame.data_ptr())
+            self.ctx.detile_frames(gathered.data_ptr(), self.world, n_frames or self.batch, self.slots, 3, self.frame.data_ptr())
         return self.frame
 
 
@@ -223,7 +225,10 @@ class FramePipeline:
             r = self.renderers[k]
             lo, hi = first[j], first[j + 1]
             st.frames = hi - lo
-            frames = gather_frame(r.local, r.vw, r.vh, self.rank, self.world, r.detile)
+            # only the frames this set rendered travel and are put together (a last, shorter set; a single frame)
+            n = hi - lo
+            part = r.local if n == B else r.local[: n * r.slots * 3]
+            frames = gather_frame(part, r.vw, r.vh, self.rank, self.world, lambda g: r.detile(g, n))
             if on_frame is not None:
                 per = r.vw * r.vh * 3
                 for f in range(lo, hi):
