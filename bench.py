@@ -222,10 +222,11 @@ def main():
     run(max(args.warmup, depth * batch))
     if batch > 1:
         run(args.steps)
-    run(1)
+    for _ in range(3):      # (the first single frames after sets of many are slower than the ones that follow)
+        run(1)
     sync()
     t0 = time.perf_counter()
-    alone = 3
+    alone = 5
     for _ in range(alone):
         run(1)
     sync()
