@@ -666,6 +666,22 @@ __global__ __launch_bounds__(RT_BLOCK) void k_detile(const uint8_t* gathered, ui
     const unsigned long long run = g / slots_per_shard;
     m.shard = (uint32_t)(run / n_frames);
     const uint32_t frame = (uint32_t)(run % n_frames);
+    // The 64 slots of a wave are one 8x8 pixel block (while the caller's slots_per_shard is a multiple of 64, as a
+    // shard's own slot count is, a wave never straddles two shards or frames): 192 consecutive bytes in, eight rows of 24 bytes out.  Where the block lies inside
+    // the frame and everything is dword-aligned, 48 lanes move one dword each instead of 64 lanes three bytes each.
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long g0 = g - lane;
+    int32_t x0, y0;
+    const bool inside0 = slot_pixel(m, vw, vh, (uint32_t)(g0 % slots_per_shard), x0, y0);
+    if (elem_bytes == 3u && (slots_per_shard & 63ull) == 0 && (vw & 3) == 0 && ((((size_t)gathered) | ((size_t)images)) & 3u) == 0 && inside0 &&
+        x0 + 8 <= vw && y0 + 8 <= vh) {
+        if (lane < 48u) {
+            const uint32_t r = lane / 6u, c = lane % 6u;
+            const uint32_t v = reinterpret_cast<const uint32_t*>(gathered + g0 * 3u)[lane];
+            reinterpret_cast<uint32_t*>(images + (((size_t)frame * (size_t)vh + (size_t)(y0 + (int32_t)r)) * (size_t)vw + (size_t)x0) * 3u)[c] = v;
+        }
+        return;
+    }
     int32_t x, y;
     if (!slot_pixel(m, vw, vh, (uint32_t)(g % slots_per_shard), x, y)) return;
     const uint8_t* src = gathered + g * elem_bytes;
