@@ -9,18 +9,23 @@
  * HOW IT IS PINNED: the reference (a Rust workspace needing a nightly
  * toolchain) cannot be built in this environment and ships no tests.  What it
  * does ship is its author's own renders, with their scene listings, in the
- * README: this restatement reproduces five of them -- byte for byte the
+ * README: this restatement reproduces five of them to the byte -- the
  * 16-sphere ring (images/readme/10_19_2021.png) and the icospheres of
  * scenes/icosahedron.sdl at 0, 2 and 5 subdivisions (11_22_2021_1..3.png:
  * mesh BVH, triangle test, normals), and all but 14 of 2,073,600 pixels of
  * the cube / mirror sphere / checkered plane / point light scene
- * (10_7_2021.png, whose cube position is random() and was fitted) -- plus
- * hand-derived analytic known-answer tests (tests/test_oracle_kat.py).
- * PARITY UNPINNED for what none of those images shows: refraction
- * (scene.rs:129-180), cubemap sampling (skybox.rs:64-119), texture
- * coordinates on meshes (mesh.rs:61-77), normals averaged over shared
- * vertices (mesh.rs:208-254), emissive materials; these rest on the
- * known-answer tests and the cited lines.
+ * (10_7_2021.png, whose cube position is random() and was fitted); and a
+ * sixth in distribution, the Cornell box of scenes/cornell.sdl
+ * (11_22_2021_5.png: glass sphere, emissive panel, an area light whose sample
+ * points the reference draws from an unseeded generator, so that no two
+ * renders are equal): the image is indistinguishable from a further render
+ * of this file with another seed, value by value, on the glass sphere alone
+ * as well, and no longer so with the sphere's index of refraction at 1.45 --
+ * plus hand-derived analytic known-answer tests (tests/test_oracle_kat.py).
+ * PARITY UNPINNED for what none of those images shows: cubemap sampling
+ * (skybox.rs:64-119), texture coordinates on meshes (mesh.rs:61-77), normals
+ * averaged over shared vertices (mesh.rs:208-254), refraction through meshes
+ * and cubes; these rest on the known-answer tests and the cited lines.
  *
  * Every function cites the reference lines it follows.  Rules kept throughout:
  * f64 where the reference is f64, f32 exactly where it is f32, no fused
