@@ -20,7 +20,9 @@
  * points the reference draws from an unseeded generator, so that no two
  * renders are equal): the image is indistinguishable from a further render
  * of this file with another seed, value by value, on the glass sphere alone
- * as well, and no longer so with the sphere's index of refraction at 1.45 --
+ * as well, and no longer so with the sphere's index of refraction at 1.45;
+ * likewise the two Cornell boxes of scenes/cornell_icosahedron.sdl
+ * (11_22_2021_6.png, _7.png: a mesh under the area light) --
  * plus hand-derived analytic known-answer tests (tests/test_oracle_kat.py).
  * PARITY UNPINNED for what none of those images shows: cubemap sampling
  * (skybox.rs:64-119), texture coordinates on meshes (mesh.rs:61-77), normals

@@ -102,9 +102,11 @@ def refraction_scene(vw=1920, vh=1080, cubemap=None):
     return s
 
 
-def cornell_scene(vw=1920, vh=1080, glass_ior=1.5):
+def cornell_scene(vw=1920, vh=1080, glass_ior=1.5, icosphere_order=None):
     """scenes/cornell.sdl (config 1; has an area light => CPU path only); glass_ior: the first sphere's index of
-    refraction, the language's default unless a test wants another picture"""
+    refraction, the language's default unless a test wants another picture.  icosphere_order: the box's contents are
+    those of scenes/cornell_icosahedron.sdl instead -- the icosphere of that many subdivisions (the file says 3), scale
+    0.5 at <0.3, -0.5, -0.5>"""
     s = Scene()
     s.set_camera(Camera(vw=vw, vh=vh, origin=(0., 0., 3.), fov=45.))
     s.add(Aabb((0., 1., 0.), (0.2, 0.0001, 0.2), sdl_material(emissivity=1.)))
@@ -115,6 +117,13 @@ def cornell_scene(vw=1920, vh=1080, glass_ior=1.5):
     s.add(sdl_plane((0., 0., -1.), (0., 0., 1.)))
     s.add(sdl_plane((-1., 0., 0.), (1., 0., 0.), sdl_material(Texture.solid((255, 0, 0)))))
     s.add(sdl_plane((1., 0., 0.), (-1., 0., 0.), sdl_material(Texture.solid((0, 255, 0)))))
+    if icosphere_order is not None:
+        soup = icosphere_soup(icosphere_order)
+        m = Mesh(sdl_material())
+        m.set_geometry(soup, np.arange(len(soup), dtype=np.uint32).reshape(-1, 3))
+        sdl_mesh(m, position=(0.3, -0.5, -0.5), scale=0.5)
+        s.add(m)
+        return s
     s.add(Sphere((-0.1, -0.6, 0.4), 0.4, sdl_material(transparency=0.6, reflectiveness=0.5, ior=glass_ior)))
     s.add(Sphere((0.3, -0.5, -0.4), 0.5, sdl_material(Texture.solid((0, 0, 255)))))
     return s
