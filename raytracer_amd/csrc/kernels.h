@@ -377,7 +377,11 @@ __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene
         if (lane_id() == 0) atomicMax(&sh->max_wave_steps, (unsigned long long)(vc.wnodes + vc.wtris));
         block_count3(cast, vc.nodes, vc.tris, &sh->rays_shadow, &sh->nodes_visited, &sh->tris_tested);
         block_count3(lane_id() == 0 ? vc.wnodes : 0, lane_id() == 0 ? vc.wtris : 0, vc.units, &sh->wave_nodes, &sh->wave_tris, &sh->units_fetched);
-    } else block_count3(cast, 0, 0, &sh->rays_shadow, nullptr, nullptr);
+    } else {
+        // the rays cast, counted per wave: a ballot and one atomic add (no LDS, no barrier at the kernel's end)
+        const unsigned long long m = __ballot(cast != 0);
+        if (m && lane_id() == 0) atomicAdd(&sh->rays_shadow, (unsigned long long)__popcll(m));
+    }
 }
 
 // k_shadow for a scene without meshes: nothing to walk as a packet, so every lane casts on its own, through the
