@@ -821,17 +821,23 @@ __device__ bool cast_any_packet(const DScene* Sp, const Ray& ray, bool active, b
                                 uint32_t budget, unsigned long long& unresolved) {
     const DScene& S = *Sp;
     const uint32_t n = S.n_linear;
-    const RT_GLOBAL DObject* objs = gptr(S.objects);
+    // the object list and the analytic objects' records are the same for the whole wave and never written while a frame
+    // renders: read through the scalar cache (constant address space), they cost neither vector loads nor registers
+    // (the closest-hit packets, shorter of scalar registers, keep their vector loads)
+    const RT_CONST DObject* objs = (const RT_CONST DObject*)uni_ptr(S.objects);
+    const RT_CONST uint32_t* linear = (const RT_CONST uint32_t*)uni_ptr(S.linear);
+    const RT_CONST double* spheres = (const RT_CONST double*)uni_ptr(S.spheres);
+    const RT_CONST double* planes = (const RT_CONST double*)uni_ptr(S.planes);
     bool blocked = false;
     unresolved = 0;
     for (uint32_t li_ = 0; li_ < n; li_++) {
-        const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
-        const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload);
+        const uint32_t oi = linear[li_];   // the objects outside the object tree, in scene order
+        const uint32_t kind = objs[oi].kind, payload = objs[oi].payload;
         if (kind == 3) continue;
         if (active && !blocked) {
             double near; bool hit;
-            if (kind == 0) hit = sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
-            else if (kind == 1) hit = plane_near(gptr(S.planes) + 8 * (size_t)payload, ray, near);
+            if (kind == 0) hit = sphere_near(spheres + 4 * (size_t)payload, ray, near);
+            else if (kind == 1) hit = plane_near(planes + 8 * (size_t)payload, ray, near);
             else if (RECIP) hit = box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
             else hit = false;
             if (hit && (!limited || near <= dist)) blocked = true;
@@ -850,8 +856,8 @@ __device__ bool cast_any_packet(const DScene* Sp, const Ray& ray, bool active, b
         if (!still) return blocked || (open && parked_blocked());
     }
     for (uint32_t li_ = 0; li_ < n; li_++) {
-        const uint32_t oi = gptr(S.linear)[li_];   // the objects outside the object tree, in scene order
-        const uint32_t kind = uni(objs[oi].kind), payload = uni(objs[oi].payload);
+        const uint32_t oi = linear[li_];   // the objects outside the object tree, in scene order
+        const uint32_t kind = objs[oi].kind, payload = objs[oi].payload;
         if (kind != 3) continue;
         unsigned long long unres = 0;
         packet_any_deferred<BUDGET>(S.meshes + payload, vc, budget, unres);
