@@ -308,8 +308,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_long_trace(const DScene* Sp, DLeve
 // The shadow ray of lit hit `hh` towards light `Lt` (sun.rs:87-94, point.rs:68-76,89-99).  cast = 0: the light casts
 // no ray here (sun with shadows off; point light beyond max_distance: LightShading::default()).
 // FULL = false: origin and direction only, for a cast that never reads 1/direction (three f64 divisions, ray.rs:17-23).
-template <bool FULL = true>
-DEV Ray shadow_ray(const RT_GLOBAL DLight* Lt, const double* hs, uint32_t stride, uint32_t hh, uint32_t& cast, bool& limited, double& dist) {
+// P: pointer to the light's record -- global, or constant address space where the light is the same for the whole wave
+template <bool FULL = true, typename P = const RT_GLOBAL DLight*>
+DEV Ray shadow_ray(P Lt, const double* hs, uint32_t stride, uint32_t hh, uint32_t& cast, bool& limited, double& dist) {
     const D3 vnear = d3(hs[hh], hs[(size_t)stride + hh], hs[2 * (size_t)stride + hh]);
     const D3 so = d3(hs[3 * (size_t)stride + hh], hs[4 * (size_t)stride + hh], hs[5 * (size_t)stride + hh]);
     const D3 lv = d3(Lt->v[0], Lt->v[1], Lt->v[2]);
@@ -354,7 +355,8 @@ __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene
     if (__ballot(have)) {   // the grid is sized for the worst case: most waves past the hit count have nothing to do
         const uint32_t hh = have ? h : 0;
         bool limited; double dist;
-        const Ray ray = shadow_ray<RECIP>(gptr(S.lights) + li, hs, stride, hh, cast, limited, dist);
+        // (one light per workgroup row: its record comes through the scalar cache)
+        const Ray ray = shadow_ray<RECIP>((const RT_CONST DLight*)uni_ptr(S.lights) + li, hs, stride, hh, cast, limited, dist);
         if (!have) cast = 0;
         // the wave's shadow rays leave neighbouring hit points towards one light: walked as a packet
         unsigned long long unresolved = 0;
