@@ -124,6 +124,16 @@ CONFIGS = {"2": (_config2, (1920, 1080)), "3": (_config3, (3840, 2160)), "3b": (
            "4": (_config4, (3840, 2160)), "5a": (_config5a, (7680, 4320)), "5b": (_config5b, (7680, 4320))}
 
 
+def default_batch(steps, world, small):
+    """Frames per set of launches when --batch is not given: half of the run's frames, at most ten whole frames' worth
+    of rays (10 x world shard frames) and at most RT_BATCH_MAX = 64; frames beyond 4K go one per set on one GPU and at
+    most `world` per set when sharded."""
+    half = (steps + 1) // 2
+    if small:
+        return max(1, min(half, 10 * world, 64))
+    return 1 if world == 1 else max(1, min(half, world))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,8 +202,7 @@ def main():
         # 7.09 ms per frame as 2 x 10, 7.18 as sets of 5, 7.24 as sets of 2 three at a time; a 1/8 shard of 20 frames is
         # 20 ms of work all told).  At most ten whole frames' worth of rays per set (17 GB of wavefront levels at 4K);
         # an 8K frame's levels take tens of GB each, so those go one frame per set.
-        half = (args.steps + 1) // 2
-        args.batch = max(1, min(half, 10 * world, 64)) if small else (1 if world == 1 else max(1, min(half, world)))   # (64: RT_BATCH_MAX)
+        args.batch = default_batch(args.steps, world, small)
     if args.frames_in_flight is None:
         args.frames_in_flight = 2
     depth, batch = max(1, args.frames_in_flight), max(1, args.batch)
