@@ -91,10 +91,15 @@ def gather_frame(local, vw, vh, rank, world, detile):
     detile: callable(gathered_tensor) -> frame, run on rank 0 only
     Returns the frame on rank 0, None elsewhere.  world == 1 needs no process group.
     """
-    import torch
-    import torch.distributed as dist
     if world == 1:
         return detile(local)
+    return gather_shards(local, rank, world, detile)
+
+
+def gather_shards(local, rank, world, detile):
+    """gather_frame's collective step: needs an initialised process group of `world` ranks (of any size, one included)"""
+    import torch
+    import torch.distributed as dist
     if local.is_cuda and dist.get_backend() == "gloo":
         # a backend that moves host memory only (rehearsals of the N > 1 path on one GPU): stage through the host
         host = local.cpu()
