@@ -86,6 +86,11 @@ def _atlas():
     return scenes.procedural_cubemap(2048)
 
 
+def _config1(vw, vh, args):
+    from raytracer_amd import scenes
+    return scenes.cornell_scene(vw, vh), "scenes/cornell.sdl (5 planes, an emissive panel, 2 spheres, one of glass; one rectangular area light of 64 sample points)"
+
+
 def _config2(vw, vh, args):
     from raytracer_amd import scenes
     return scenes.refraction_scene(vw, vh, cubemap=_atlas()), "scenes/refraction.sdl (3 spheres, 1 plane, sun, 8192x6144 cubemap)"
@@ -120,7 +125,7 @@ def _config5b(vw, vh, args):
 
 
 # name -> (builder, default resolution)
-CONFIGS = {"2": (_config2, (1920, 1080)), "3": (_config3, (3840, 2160)), "3b": (_config3b, (3840, 2160)),
+CONFIGS = {"1": (_config1, (1920, 1080)), "2": (_config2, (1920, 1080)), "3": (_config3, (3840, 2160)), "3b": (_config3b, (3840, 2160)),
            "4": (_config4, (3840, 2160)), "5a": (_config5a, (7680, 4320)), "5b": (_config5b, (7680, 4320))}
 
 
@@ -140,7 +145,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="4", choices=sorted(CONFIGS),
-                    help="BASELINE configuration: 2 refraction.sdl 1080p; 3 fedora.sdl 4K; 3b the teapot standing in for bunny.sdl 4K; "
+                    help="BASELINE configuration: 1 cornell.sdl 1080p (area light); 2 refraction.sdl 1080p; 3 fedora.sdl 4K; 3b the teapot standing in for bunny.sdl 4K; "
                          "4 (default, the headline) 1M-triangle terrain 4K; 5a huge_grid.sdl 8K; 5b terrain.sdl 8K")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)

@@ -36,7 +36,7 @@ extern "C" {
  *      skybox.rs:8-11, material.rs:108-117) -------------------------------- */
 enum { RT_OBJ_SPHERE = 0, RT_OBJ_PLANE = 1, RT_OBJ_BOX = 2, RT_OBJ_MESH = 3 };
 enum { RT_TEX_SOLID = 0, RT_TEX_IMAGE = 1, RT_TEX_CHECKER = 2 };
-enum { RT_LIGHT_SUN = 0, RT_LIGHT_POINT = 1, RT_LIGHT_AREA = 2 /* CPU only */ };
+enum { RT_LIGHT_SUN = 0, RT_LIGHT_POINT = 1, RT_LIGHT_AREA = 2 };
 enum { RT_SKY_SOLID = 0, RT_SKY_NORMAL = 1, RT_SKY_CUBEMAP = 2 };
 enum { RT_AREA_SPHERE = 0, RT_AREA_RECTANGLE = 1 };
 
@@ -136,7 +136,7 @@ typedef struct rt_light {
     double   v[3];                /* SUN: vector; POINT: position; AREA sphere: centre */
     double   shadow_coefficient;  /* SUN only */
     double   max_distance;        /* POINT / AREA */
-    /* AREA only (not supported on the device) */
+    /* AREA only */
     uint32_t area_surface;        /* RT_AREA_* */
     uint32_t area_iterations;
     double   area_radius;
@@ -237,8 +237,18 @@ const char* rt_last_error(const rt_ctx* ctx);
  * frame (sdl/src/main.rs:84-92 sequence mode).  A mesh tree too deep for the
  * traversal stacks (about 64 levels) is replaced by a balanced tree over the
  * same leaves in the same order: same hits, same winners between equal
- * distances.  RT_ERR_UNSUPPORTED for area lights. */
+ * distances.  Lights and area-light samples together (area_iterations per
+ * area light, area.rs:117) may number 65535 at most: RT_ERR_UNSUPPORTED. */
 int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* scene);
+
+/* Seed of the area lights' sample points.  No counterpart in the reference:
+ * lighting/area.rs:121 draws every sample point from an unseeded thread
+ * generator, so two of its renders of one scene differ; here a sample point
+ * is a function of (seed, pixel, the ray's place in the pixel's tree of rays,
+ * light, sample number), the same on the device and in the CPU oracle, and a
+ * frame is repeatable.  Applies to the scene in place and to later uploads.
+ * Default 0x9E3779B97F4A7C15. */
+int rt_set_area_seed(rt_ctx* ctx, uint64_t seed);
 
 /* Replaces Scene::render (scene.rs:220-246).
  *   rgb_out     vw*vh*3 bytes, row-major, top-left origin (host memory)

@@ -494,13 +494,26 @@ Color skybox_ray_color(const Scene& sc, const Ray& ray) {
 /* lighting/mod.rs:16-31 */
 struct LightShading { double diffuse = 0., specular = 0., intensity = 0.; };
 
-/* area.rs:121 uses an unseeded thread RNG; this seeded stand-in makes the CPU
- * path runnable for area-light scenes but cannot match the reference's draws. */
+/* area.rs:121 draws from an unseeded thread generator.  This stand-in makes area-light scenes runnable and
+ * repeatable, but cannot match the reference's draws.  It is counter-based, so that a renderer which visits the rays
+ * of a pixel in another order (level by level instead of depth first) draws the same numbers: every ray carries a
+ * key -- a primary ray's from the seed and its pixel index, a child's from its parent's and its kind -- and the draws
+ * of sample `it` of light `li` at the ray's hit are a splitmix64 sequence started from (key, li, it). */
+inline uint64_t rng_mix(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline uint64_t rng_key_primary(uint64_t seed, uint64_t pixel) { return rng_mix(seed ^ rng_mix(pixel)); }
+enum : uint64_t { RNG_CHILD_TRANSMIT = 1, RNG_CHILD_REFLECT = 2 };
+inline uint64_t rng_key_child(uint64_t key, uint64_t kind) { return rng_mix(key + kind); }
 struct Rng {
     uint64_t s;
+    static Rng for_sample(uint64_t key, uint32_t li, uint32_t it) { return Rng{rng_mix(key ^ rng_mix(((uint64_t)li << 32) | it))}; }
     double next_pm1() {   /* uniform in [-1, 1] */
-        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
-        return (double)(s >> 11) * (2.0 / 9007199254740991.0) - 1.0;
+        s += 0xD1342543DE82EF95ull;
+        return (double)(rng_mix(s) >> 11) * (2.0 / 9007199254740991.0) - 1.0;
     }
 };
 
@@ -527,7 +540,7 @@ LightShading point_like(const Scene& sc, const rt_light& L, V3 position, const R
     return out;
 }
 
-LightShading light_shading(const Scene& sc, const rt_light& L, const Ray& ray, const Hit& hit, Rng& rng) {
+LightShading light_shading(const Scene& sc, const rt_light& L, uint32_t li, const Ray& ray, const Hit& hit, uint64_t key) {
     switch (L.kind) {
         case RT_LIGHT_SUN: {                                                       // sun.rs:72-97
             V3 lvec = -v3(L.v[0], L.v[1], L.v[2]);
@@ -554,6 +567,7 @@ LightShading light_shading(const Scene& sc, const rt_light& L, const Ray& ray, c
         case RT_LIGHT_AREA: {                                                      // area.rs:114-166
             std::vector<LightShading> samples;
             for (uint32_t it = 0; it < L.area_iterations; it++) {
+                Rng rng = Rng::for_sample(key, li, it);
                 V3 pos;
                 if (L.area_surface == RT_AREA_SPHERE) {                            // area.rs:30-40
                     double x = rng.next_pm1(), y = rng.next_pm1(), z = rng.next_pm1();
@@ -587,7 +601,7 @@ LightShading light_shading(const Scene& sc, const rt_light& L, const Ray& ray, c
 }
 
 /* scene.rs:85-206 */
-Color trace_ray(const Scene& sc, const Ray& ray, uint32_t depth, Rng& rng, uint32_t* id_out) {
+Color trace_ray(const Scene& sc, const Ray& ray, uint32_t depth, uint64_t key, uint32_t* id_out) {
     if (tl_counts && depth < 8) tl_counts->rays_per_level[depth]++;
     uint32_t oi; Hit hit;
     if (!cast_ray_once(sc, ray, oi, hit)) {
@@ -606,7 +620,7 @@ Color trace_ray(const Scene& sc, const Ray& ray, uint32_t depth, Rng& rng, uint3
     for (uint32_t li = 0; li < sc.d->n_lights; li++) {
         const rt_light& L = sc.d->lights[li];
         V3 lcol = to_v3(Color{L.color[0], L.color[1], L.color[2]});
-        LightShading sh = light_shading(sc, L, ray, hit, rng);
+        LightShading sh = light_shading(sc, L, li, ray, hit, key);
         V3 diffuse = lcol * sh.diffuse;
         V3 specular = lcol * (sh.specular * L.specular_strength);
         sum_vecs = sum_vecs + (diffuse + specular) * sh.intensity;
@@ -619,7 +633,7 @@ Color trace_ray(const Scene& sc, const Ray& ray, uint32_t depth, Rng& rng, uint3
         V3 transparency_color = color;
         if (ior == 1.) {
             COUNT(rays_transmit);
-            Color thru = trace_ray(sc, ray_new(hit.vfar, ray.direction), depth + 1, rng, nullptr);
+            Color thru = trace_ray(sc, ray_new(hit.vfar, ray.direction), depth + 1, rng_key_child(key, RNG_CHILD_TRANSMIT), nullptr);
             transparency_color = to_v3(thru);
         } else {
             V3 ref_vec;
@@ -638,7 +652,7 @@ Color trace_ray(const Scene& sc, const Ray& ray, uint32_t depth, Rng& rng, uint3
                         V3 exit_ref_vec;
                         if (refraction_vec(ray_new(ref_hit.vfar + ref_vec * EPSILON, ref_vec), -exit_hit.normal, ior, 1., exit_ref_vec)) {
                             COUNT(rays_transmit);
-                            Color ref_col = trace_ray(sc, ray_new(ref_hit.vfar + exit_ref_vec * EPSILON, exit_ref_vec), depth + 1, rng, nullptr);
+                            Color ref_col = trace_ray(sc, ray_new(ref_hit.vfar + exit_ref_vec * EPSILON, exit_ref_vec), depth + 1, rng_key_child(key, RNG_CHILD_TRANSMIT), nullptr);
                             transparency_color = to_v3(ref_col);
                         }
                     }
@@ -649,7 +663,7 @@ Color trace_ray(const Scene& sc, const Ray& ray, uint32_t depth, Rng& rng, uint3
             double d = dot(-ray.direction, hit.normal);
             d = d * d;                                                            /* powi(2) */
             COUNT(rays_reflect);
-            Color reflected = trace_ray(sc, reflect(ray, hit.vnear + hit.normal * EPSILON, hit.normal), depth + 1, rng, nullptr);
+            Color reflected = trace_ray(sc, reflect(ray, hit.vnear + hit.normal * EPSILON, hit.normal), depth + 1, rng_key_child(key, RNG_CHILD_REFLECT), nullptr);
             transparency_color = vlerp(transparency_color, to_v3(reflected), 1. - d);
         }
         color = vlerp(color, transparency_color, transparency);
@@ -657,7 +671,7 @@ Color trace_ray(const Scene& sc, const Ray& ray, uint32_t depth, Rng& rng, uint3
 
     if (reflectiveness > EPSILON && depth < max_depth && transparency < EPSILON) {
         COUNT(rays_reflect);
-        Color reflected = trace_ray(sc, reflect(ray, hit.vnear + hit.normal * EPSILON, hit.normal), depth + 1, rng, nullptr);
+        Color reflected = trace_ray(sc, reflect(ray, hit.vnear + hit.normal * EPSILON, hit.normal), depth + 1, rng_key_child(key, RNG_CHILD_REFLECT), nullptr);
         color = vlerp(color, to_v3(reflected), reflectiveness);
     }
 
@@ -667,11 +681,11 @@ Color trace_ray(const Scene& sc, const Ray& ray, uint32_t depth, Rng& rng, uint3
 }
 
 /* scene.rs:210-217 */
-Color trace_pixel(const Scene& sc, int32_t x, int32_t y, Rng& rng, uint32_t* id_out) {
+Color trace_pixel(const Scene& sc, int32_t x, int32_t y, uint64_t key, uint32_t* id_out) {
     Ray ray = ray_new(v3(sc.d->camera.origin[0], sc.d->camera.origin[1], sc.d->camera.origin[2]),
                       direction_at(sc.d->camera, (double)x, (double)y));
     COUNT(rays_primary);
-    return trace_ray(sc, ray, 0, rng, id_out);
+    return trace_ray(sc, ray, 0, key, id_out);
 }
 
 int validate(const rt_scene_desc* d) {
@@ -739,9 +753,8 @@ int rt_cpu_render_pixels(const rt_scene_desc* d, int n_threads, uint64_t n, cons
             uint64_t e = std::min(n, b + chunk);
             for (uint64_t k = b; k < e; k++) {
                 uint64_t i = pixels ? pixels[k] : k;
-                Rng rng{sc.area_seed ^ (i * 0xD1342543DE82EF95ull + 1)};
                 uint32_t ids[2];
-                Color c = trace_pixel(sc, (int32_t)(i % (uint64_t)vw), (int32_t)(i / (uint64_t)vw), rng, ids);   // scene.rs:241
+                Color c = trace_pixel(sc, (int32_t)(i % (uint64_t)vw), (int32_t)(i / (uint64_t)vw), rng_key_primary(sc.area_seed, i), ids);   // scene.rs:241
                 rgb_out[3 * k] = c.r; rgb_out[3 * k + 1] = c.g; rgb_out[3 * k + 2] = c.b;
                 if (prim_id_out) { prim_id_out[2 * k] = ids[0]; prim_id_out[2 * k + 1] = ids[1]; }
             }

@@ -86,7 +86,7 @@ _host = None
 GPU_SYMBOLS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload", "rt_render",
     "rt_shard_pixels", "rt_supertile", "rt_render_shard", "rt_detile", "rt_cast_rays", "rt_cast_rays_noalloc",
-    "rt_render_shard_batch", "rt_detile_frames",
+    "rt_render_shard_batch", "rt_detile_frames", "rt_set_area_seed",
 ]
 
 
@@ -120,6 +120,8 @@ def gpu():
         L.rt_cast_rays.restype = C.c_int
         L.rt_cast_rays_noalloc.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_cast_rays_noalloc.restype = C.c_int
+        L.rt_set_area_seed.argtypes = [C.c_void_p, C.c_uint64]
+        L.rt_set_area_seed.restype = C.c_int
         _gpu = L
     return _gpu
 

@@ -80,6 +80,50 @@ DEV double rt_powi(double a, int b) {
 DEV double lerp(double a, double b, double c) { return a + (b - a) * c; }                      // math/mod.rs:17-19
 DEV D3 vlerp(D3 a, D3 b, double t) { return d3(lerp(a.x, b.x, t), lerp(a.y, b.y, t), lerp(a.z, b.z, t)); }
 
+// Sample points of area lights.  area.rs:121 draws from an unseeded thread generator; here the draws are a function of
+// (seed, pixel, the ray's place in the pixel's tree of rays, light, sample), so that they do not depend on the order
+// in which rays are traced: every ray carries a key -- a primary ray's from the seed and its pixel index, a child's
+// from its parent's and its kind -- and the draws of sample `it` of light `li` at the ray's hit are a splitmix64
+// sequence started from (key, li, it).
+DEV unsigned long long rng_mix(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+DEV unsigned long long rng_key_primary(unsigned long long seed, unsigned long long pixel) { return rng_mix(seed ^ rng_mix(pixel)); }
+#define RT_RNG_CHILD_TRANSMIT 1ull
+#define RT_RNG_CHILD_REFLECT 2ull
+DEV unsigned long long rng_key_child(unsigned long long key, unsigned long long kind) { return rng_mix(key + kind); }
+struct AreaRng {
+    unsigned long long s;
+    DEV double next_pm1() {   // uniform in [-1, 1]
+        s += 0xD1342543DE82EF95ull;
+        return (double)(rng_mix(s) >> 11) * (2.0 / 9007199254740991.0) - 1.0;
+    }
+};
+// AreaSurface::sample (area.rs:25-50) for sample `it` of light `li` at the hit of the ray with this key
+template <typename P>
+DEV D3 area_sample(P Lt, unsigned long long key) {
+    AreaRng rng = {rng_mix(key ^ rng_mix(((unsigned long long)Lt->area_li << 32) | Lt->area_it))};
+    if (Lt->area_surface == 0) {                                                    // Sphere, area.rs:30-40
+        double x = rng.next_pm1(), y = rng.next_pm1(), z = rng.next_pm1();
+        const double mag = sqrt(x * x + y * y + z * z);
+        const double d = (rng.next_pm1() * 0.5 + 0.5) / mag;
+        x *= d; y *= d; z *= d;
+        return d3(x, y, z) * Lt->area_radius + d3(Lt->v[0], Lt->v[1], Lt->v[2]);
+    }
+    const double tx = rng.next_pm1() * 0.5 + 0.5;                                    // Rectangle, area.rs:41-48; blerp: math/mod.rs:22-26
+    const double ty = rng.next_pm1() * 0.5 + 0.5;
+    const D3 c00 = d3(Lt->area_corners[0][0], Lt->area_corners[0][1], Lt->area_corners[0][2]);
+    const D3 c10 = d3(Lt->area_corners[1][0], Lt->area_corners[1][1], Lt->area_corners[1][2]);
+    const D3 c01 = d3(Lt->area_corners[2][0], Lt->area_corners[2][1], Lt->area_corners[2][2]);
+    const D3 c11 = d3(Lt->area_corners[3][0], Lt->area_corners[3][1], Lt->area_corners[3][2]);
+    const D3 a = c00 * (1. - tx) + c10 * tx;
+    const D3 b = c01 * (1. - tx) + c11 * tx;
+    return a * (1. - ty) + b * ty;
+}
+
 // material.rs:38-44 (Color::newf) packed r | g<<8 | b<<16
 DEV uint32_t newf(double r, double g, double b) {
     return as_u8(clampd(r, 0., 1.) * 255.0) | (as_u8(clampd(g, 0., 1.) * 255.0) << 8) | (as_u8(clampd(b, 0., 1.) * 255.0) << 16);

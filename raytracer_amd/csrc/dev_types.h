@@ -100,9 +100,17 @@ struct DLight {
     uint32_t shadows, _pad;
     double col[3];             // colour / 255 (vector.rs:216-224)
     double intensity, specular_strength;
-    double v[3];               // sun: vector; point: position
+    double v[3];               // sun: vector; point: position; area sphere: centre
     double shadow_coefficient, max_distance;
+    // An area light (area.rs:56-81) takes one record per sample point, in a row: the record of sample `area_it` of
+    // `area_n`, all with the light's own index `area_li` in the scene's list (kind RT_DLIGHT_AREA_SAMPLE), so that the
+    // shadow kernels find one cast per record as for the other lights.  A light of no samples takes one record of kind
+    // RT_DLIGHT_AREA_EMPTY.
+    uint32_t area_surface, area_it, area_n, area_li;
+    double area_radius;
+    double area_corners[4][3];
 };
+enum { RT_DLIGHT_SUN = 0, RT_DLIGHT_POINT = 1, RT_DLIGHT_AREA_SAMPLE = 2, RT_DLIGHT_AREA_EMPTY = 3 };
 
 // camera (camera.rs:55-67): rot = from_euler_xyz(-pitch, yaw, 0) hoisted to the host
 struct DCamera {
@@ -132,6 +140,9 @@ struct DScene {
     uint32_t sky_kind, sky_rgb;     // packed solid colour
     uint32_t sky_w, sky_h;
     const uint8_t* sky_pix;
+    // area lights: whether the scene has any (only then do rays carry keys), and the seed of their sample points
+    unsigned long long area_seed;
+    uint32_t has_area, _pad_area;
 };
 
 // Structure-of-arrays state of one wavefront level: every ray of one
@@ -149,6 +160,7 @@ struct DLevel {
     uint32_t* child0; uint32_t* child1;           // index in the next level (transmission, reflection)
     uint32_t* base_flags;                         // base colour rgb | flags << 24
     uint32_t* result;                             // final colour of this trace_ray call, packed rgb
+    unsigned long long* key;                      // what the ray's area-light sample points are drawn from (written in scenes with area lights only)
 };
 
 enum { NF_DONE = 1, NF_TRANSPARENT = 2, NF_T_REFLECT = 4, NF_REFLECT = 8, NF_EMISSIVE = 16 };

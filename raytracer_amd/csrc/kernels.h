@@ -85,6 +85,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(const DScene* Sp, const DC
     }
     L.hit_obj[i] = RT_NONE;
     store_ray(L, i, ld3(cam.cam_o), camera_direction(cam, (double)x, (double)y));
+    if (S.has_area) L.key[i] = rng_key_primary(S.area_seed, (unsigned long long)y * (unsigned long long)S.vw + (unsigned long long)x);
 }
 
 // A level's size as its kernels see it: `n` is what the launch was sized for -- the size itself when the host knows
@@ -309,17 +310,26 @@ __global__ __launch_bounds__(RT_BLOCK) void k_long_trace(const DScene* Sp, DLeve
 // no ray here (sun with shadows off; point light beyond max_distance: LightShading::default()).
 // FULL = false: origin and direction only, for a cast that never reads 1/direction (three f64 divisions, ray.rs:17-23).
 // P: pointer to the light's record -- global, or constant address space where the light is the same for the whole wave
-template <bool FULL = true, typename P = const RT_GLOBAL DLight*>
-DEV Ray shadow_ray(P Lt, const double* hs, uint32_t stride, uint32_t hh, uint32_t& cast, bool& limited, double& dist) {
+// AREA: the scene has area lights: a record may be one sample point of one (area.rs:117-153: a point light at a point
+// drawn from the hit ray's key, keys[hitlist[hh]]) or stand for an area light without samples (no cast).  A sample
+// beyond max_distance casts nothing, like a point light; the reference stops the light's loop there, and k_light takes
+// the casts of the samples after it off the count again.
+template <bool FULL = true, typename P = const RT_GLOBAL DLight*, bool AREA = true>
+DEV Ray shadow_ray(P Lt, const double* hs, uint32_t stride, uint32_t hh, uint32_t& cast, bool& limited, double& dist,
+                   const uint32_t* hitlist = nullptr, const unsigned long long* keys = nullptr) {
     const D3 vnear = d3(hs[hh], hs[(size_t)stride + hh], hs[2 * (size_t)stride + hh]);
     const D3 so = d3(hs[3 * (size_t)stride + hh], hs[4 * (size_t)stride + hh], hs[5 * (size_t)stride + hh]);
-    const D3 lv = d3(Lt->v[0], Lt->v[1], Lt->v[2]);
+    D3 lv = d3(Lt->v[0], Lt->v[1], Lt->v[2]);
     limited = false; dist = 0.;
     D3 dir;
-    if (Lt->kind == 0) {
+    if (Lt->kind == RT_DLIGHT_SUN) {
         cast = Lt->shadows ? 1u : 0u;
         dir = -lv;
+    } else if (AREA && (Lt->kind == RT_DLIGHT_AREA_EMPTY || (Lt->kind == RT_DLIGHT_AREA_SAMPLE && (!keys || !hitlist)))) {
+        cast = 0u;
+        dir = d3(0., 0., 1.);
     } else {
+        if (AREA && Lt->kind == RT_DLIGHT_AREA_SAMPLE) lv = area_sample(Lt, keys[hitlist[hh]]);
         D3 lvec = lv - vnear;
         dist = magnitude(lvec);
         cast = dist > Lt->max_distance ? 0u : 1u;
@@ -343,9 +353,10 @@ DEV Ray shadow_ray(P Lt, const double* hs, uint32_t stride, uint32_t hh, uint32_
 #endif
 // RECIP = false: no cube stands outside the object tree and there is no object tree, so nothing in the cast reads
 // 1/direction (aabb.rs:18-67 is its only reader here) and the ray comes without it.
-template <bool COUNT, bool BUDGET, bool RECIP = true>
-__global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
-                                                                                                          DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
+// AREA: see shadow_ray (kernels of their own, k_shadow_area: the other scenes' kernels stay as they are)
+template <bool COUNT, bool BUDGET, bool RECIP, bool AREA>
+DEV void shadow_body(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
+                     DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp, const unsigned long long* keys) {
     const uint32_t h = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t li = blockIdx.y;
     const DScene& S = *Sp;
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene
         const uint32_t hh = have ? h : 0;
         bool limited; double dist;
         // (one light per workgroup row: its record comes through the scalar cache)
-        const Ray ray = shadow_ray<RECIP>((const RT_CONST DLight*)uni_ptr(S.lights) + li, hs, stride, hh, cast, limited, dist);
+        const Ray ray = shadow_ray<RECIP, const RT_CONST DLight*, AREA>((const RT_CONST DLight*)uni_ptr(S.lights) + li, hs, stride, hh, cast, limited, dist, hitlist, keys);
         if (!have) cast = 0;
         // the wave's shadow rays leave neighbouring hit points towards one light: walked as a packet
         unsigned long long unresolved = 0;
@@ -386,18 +397,31 @@ __global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene
     }
 }
 
+template <bool COUNT, bool BUDGET, bool RECIP = true>
+__global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
+                                                                                                          DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp) {
+    shadow_body<COUNT, BUDGET, RECIP, false>(Sp, hitlist, hs, occ, stride, C, LC, longlist, lp, nullptr);
+}
+// the same for a scene with area lights: `keys` are the level's ray keys
+template <bool COUNT, bool BUDGET>
+__global__ __launch_bounds__(RT_BLOCK) RT_SHADOW_ATTR void k_shadow_area(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
+                                                                                                               DCounters* C, DLevelCounts* LC, uint32_t* longlist, LongParams lp,
+                                                                                                               const unsigned long long* keys) {
+    shadow_body<COUNT, BUDGET, true, true>(Sp, hitlist, hs, occ, stride, C, LC, longlist, lp, keys);
+}
+
 // k_shadow for a scene without meshes: nothing to walk as a packet, so every lane casts on its own, through the
 // object tree's wide records with a stack of its own.
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow_lanes(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
-                                                           DCounters* C, const DLevelCounts* LC) {
+                                                           DCounters* C, const DLevelCounts* LC, const unsigned long long* keys) {
     const uint32_t h = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t li = blockIdx.y;
     const DScene& S = *Sp;
     uint32_t cast = 0;
     if (h < (uint32_t)LC->hit_count) {
         bool limited; double dist;
-        const Ray ray = shadow_ray(gptr(S.lights) + li, hs, stride, h, cast, limited, dist);
+        const Ray ray = shadow_ray(gptr(S.lights) + li, hs, stride, h, cast, limited, dist, hitlist, keys);
         if (cast) occ[(size_t)li * stride + hitlist[h]] = cast_any_analytic(S, ray, limited, dist) ? 1 : 0;
     }
     block_count3(cast, 0, 0, &my_shard(C)->rays_shadow, nullptr, nullptr);
@@ -406,7 +430,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_lanes(const DScene* Sp, con
 // The listed long shadow rays, RT_SEGS lanes each: any piece that finds a blocker sets the ray's byte.
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_long_shadow(const DScene* Sp, const uint32_t* hitlist, const double* hs, uint8_t* occ, uint32_t stride,
-                                                          DCounters* C, const DLevelCounts* LC, const uint32_t* longlist) {
+                                                          DCounters* C, const DLevelCounts* LC, const uint32_t* longlist, const unsigned long long* keys) {
     const DScene& S = *Sp;
     const uint32_t n_long = (uint32_t)LC->long_shadow;
     const uint32_t per_block = RT_BLOCK / RT_SEGS;
@@ -417,12 +441,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_long_shadow(const DScene* Sp, cons
         const uint32_t hh = longlist[2 * (size_t)j], li = longlist[2 * (size_t)j + 1];
         if (li >= S.n_lights) continue;
         uint32_t cast; bool limited; double dist;
-        const Ray ray = shadow_ray(gptr(S.lights) + li, hs, stride, hh, cast, limited, dist);
+        const Ray ray = shadow_ray(gptr(S.lights) + li, hs, stride, hh, cast, limited, dist, hitlist, keys);
         if (cast && cast_any_seg(S, ray, limited, dist, vc, k, RT_SEGS)) occ[(size_t)li * stride + hitlist[hh]] = 1;
     }
     if (COUNT) { DShard* sh = my_shard(C); block_count3(vc.nodes, vc.tris, vc.units, &sh->nodes_visited, &sh->tris_tested, &sh->units_fetched); }
 }
 
+DEV bool point_shading(const DLight& Lt, D3 pos, const Ray& ray, const Hit& hit, bool shadowed, double& diffuse, double& specular, double& intensity);
 // One light's contribution (lighting/sun.rs:72-97, point.rs:66-105) given its shadow cast's result
 DEV void light_shading(const DLight& Lt, const Ray& ray, const Hit& hit, bool shadowed,
                        double& diffuse, double& specular, double& intensity) {
@@ -436,9 +461,16 @@ DEV void light_shading(const DLight& Lt, const Ray& ray, const Hit& hit, bool sh
         intensity = Lt.intensity;
         return;
     }
-    D3 lvec = ld3(Lt.v) - hit.vnear;
+    point_shading(Lt, ld3(Lt.v), ray, hit, shadowed, diffuse, specular, intensity);
+}
+
+// point.rs:66-105 (and the loop body of area.rs:117-159) for a light at `pos`; false: the hit is beyond max_distance
+DEV bool point_shading(const DLight& Lt, D3 pos, const Ray& ray, const Hit& hit, bool shadowed,
+                       double& diffuse, double& specular, double& intensity) {
+    const double FMAX = 1.7976931348623157e308;
+    D3 lvec = pos - hit.vnear;
     double dist = magnitude(lvec);
-    if (dist > Lt.max_distance) { diffuse = 0.; specular = 0.; intensity = 0.; return; }   // LightShading::default()
+    if (dist > Lt.max_distance) { diffuse = 0.; specular = 0.; intensity = 0.; return false; }   // LightShading::default()
     lvec = div_by_norm(lvec, dist);
     diffuse = clampd(dot(hit.normal, lvec), 0., FMAX);
     D3 halfway = normalize(lvec - ray.d);
@@ -446,6 +478,7 @@ DEV void light_shading(const DLight& Lt, const Ray& ray, const Hit& hit, bool sh
     if (shadowed) { diffuse *= 0.; specular *= 0.; }
     double q = dist / RT_METER;
     intensity = Lt.intensity / (q * q);
+    return true;
 }
 
 // What a hit spawns (scene.rs:129-196): the transmitted ray (child 0) and the reflected ray (child 1), the blend
@@ -549,6 +582,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(MESHRE
     }
     if (want0) { store_ray(N, s0, c0o, c0d); N.hit_obj[s0] = RT_NONE; }
     if (want1) { store_ray(N, s1, c1o, c1d); N.hit_obj[s1] = RT_NONE; }
+    if (S.has_area && (want0 || want1)) {
+        const unsigned long long key = L.key[i];
+        if (want0) N.key[s0] = rng_key_child(key, RT_RNG_CHILD_TRANSMIT);
+        if (want1) N.key[s1] = rng_key_child(key, RT_RNG_CHILD_REFLECT);
+    }
     DShard* sh = my_shard(C);
     block_count3(want0 ? 1u : 0u, want1 ? 1u : 0u, 0, &sh->rays_transmit, &sh->rays_reflect, nullptr);
     if (COUNT) block_count3(vc.nodes, vc.tris, vc.units, &sh->nodes_visited, &sh->tris_tested, &sh->units_fetched);
@@ -579,7 +617,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_count_children(const DScene* Sp, D
 // The lit colour of every hit that k_spawn left pending (scene.rs:102-122), from the shadow casts' results.  A hit
 // without children is final here; the others keep the colour for k_resolve.
 // (64 registers, 8 waves per SIMD, no spills; 80 when left alone)
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_light(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, const uint8_t* occ, uint32_t stride) {
+// AREA: the scene has area lights (a variant of its own).  The records of one area light's samples stand in a row;
+// their shadings are summed as area.rs:161-165 sums them (each of the three sums in sample order) and divided by the
+// number of samples -- none: 0 / 0, as there.  The first sample beyond max_distance makes the light's shading
+// LightShading::default() (area.rs:126-128) and ends its loop there: the samples after it cast nothing in the
+// reference, so what k_shadow counted for them is taken off again.
+template <bool AREA>
+DEV void light_body(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, const uint8_t* occ, uint32_t stride, DCounters* C) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= level_size(n, n_dev)) return;
     const uint32_t bf = L.base_flags[i];
@@ -593,10 +637,30 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     const uint32_t base_rgb = bf & 0xFFFFFFu;
     D3 color = to_d3(base_rgb);
     D3 sum = ld3(S.ambient);                                   // scene.rs:110-120
+    unsigned long long uncast = 0;
     for (uint32_t li = 0; li < S.n_lights; li++) {
         const DLight& Lt = S.lights[li];
         double diff = 0., spec = 0., inten = 0.;
-        light_shading(Lt, ray, hit, occ[(size_t)li * stride + i] != 0, diff, spec, inten);
+        if (AREA && Lt.kind == RT_DLIGHT_AREA_EMPTY) {
+            diff = 0. / 0.; spec = diff; inten = diff;
+        } else if (AREA && Lt.kind == RT_DLIGHT_AREA_SAMPLE) {
+            // (the row's records differ in area_it only)
+            const unsigned long long key = L.key[i];
+            double sd = 0., ss = 0., si = 0.;
+            bool far = false;
+            const uint32_t rows = Lt.area_n < S.n_lights - li ? Lt.area_n : S.n_lights - li;
+            for (uint32_t it = 0; it < rows; it++) {
+                const DLight& Ls = S.lights[li + it];
+                double d1, s1, i1;
+                const bool near = point_shading(Ls, area_sample(&Ls, key), ray, hit, occ[(size_t)(li + it) * stride + i] != 0, d1, s1, i1);
+                if (far) { if (near) uncast++; }
+                else if (!near) far = true;
+                else { sd += d1; ss += s1; si += i1; }
+            }
+            if (!far) { const double cnt = (double)rows; diff = sd / cnt; spec = ss / cnt; inten = si / cnt; }
+            li += rows - 1;
+        } else
+            light_shading(Lt, ray, hit, occ[(size_t)li * stride + i] != 0, diff, spec, inten);
         D3 lcol = ld3(Lt.col);
         D3 dv = lcol * diff;
         D3 sv = lcol * (spec * Lt.specular_strength);
@@ -612,6 +676,13 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     } else {
         L.lit[0][i] = color.x; L.lit[1][i] = color.y; L.lit[2][i] = color.z;
     }
+    if (AREA && uncast) atomicAdd(&my_shard(C)->rays_shadow, 0ull - uncast);   // (the shards are summed modulo 2^64)
+}
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_light(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, const uint8_t* occ, uint32_t stride) {
+    light_body<false>(Sp, L, n, n_dev, occ, stride, nullptr);
+}
+__global__ __launch_bounds__(RT_BLOCK) void k_light_area(const DScene* Sp, DLevel L, uint32_t n, const unsigned long long* n_dev, const uint8_t* occ, uint32_t stride, DCounters* C) {
+    light_body<true>(Sp, L, n, n_dev, occ, stride, C);
 }
 
 // Folds one level into its parents' view: scene.rs:176-205 on the children's

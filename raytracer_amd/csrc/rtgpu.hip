@@ -127,7 +127,9 @@ struct rt_ctx {
     bool serial = false;                              // RTGPU_SERIAL=1: everything on the main stream (profiling: kernels do not overlap)
     uint32_t long_below = 300000u;                  // ... applied to launches of fewer rays than this
     int count_visits = 0;                             // RTGPU_COUNT_VISITS: bit 0 k_trace, bit 1 k_shadow, bit 2 k_shade instrumented
-    uint32_t n_lights = 0;
+    uint32_t n_lights = 0;                            // light records on the device: one per sun and point light, one per sample of an area light
+    bool has_area = false;                            // the scene has area lights
+    uint64_t area_seed = 0x9E3779B97F4A7C15ull;       // seed of their sample points (rt_set_area_seed)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // level sizes of the last frame rendered for (shard, n_shards, vw, vh, max_depth): what the next such frame is given room for
     typedef std::tuple<uint32_t, uint32_t, int32_t, int32_t, uint32_t, uint32_t> LearnedKey;
@@ -567,9 +569,9 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc, bool rebalanc
 }
 
 size_t level_bytes(size_t cap) {
-    // 6+2+3+3 doubles, 2 floats, 6 u32 per slot; each array padded to 256 B
+    // 6+2+3+3 doubles, the key, 2 floats, 6 u32 per slot; each array padded to 256 B
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return 14 * pad(cap * 8) + 2 * pad(cap * 4) + 6 * pad(cap * 4);
+    return 15 * pad(cap * 8) + 2 * pad(cap * 4) + 6 * pad(cap * 4);
 }
 
 int ensure_level(rt_ctx* c, size_t idx, size_t cap) {
@@ -594,6 +596,7 @@ int ensure_level(rt_ctx* c, size_t idx, size_t cap) {
     // the lit colour takes the normal's place: k_light, the normal's last reader, is the colour's writer (same thread, same slot)
     for (int k = 0; k < 3; k++) L.lit[k] = L.nrm[k];
     L.w_t = takeD(); L.w_r = takeD(); L.emis = takeD();
+    L.key = reinterpret_cast<unsigned long long*>(takeD());
     L.hit_u = takeF(); L.hit_v = takeF();
     L.hit_obj = takeU(); L.hit_prim = takeU(); L.child0 = takeU(); L.child1 = takeU(); L.base_flags = takeU(); L.result = takeU();
     return RT_OK;
@@ -793,6 +796,7 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
         DCounters* dc = c->dcounters + depth;
         uint32_t* long_trace = static_cast<uint32_t*>(W.long_trace);
         uint32_t* long_shadow = static_cast<uint32_t*>(W.long_shadow);
+        const unsigned long long* keys = c->levels[depth].lv.key;   // (ensure_level(depth) ran before this level was spawned into)
         // budgets only where the launch is small enough for its slowest wave to set its duration: in a large
         // launch the other waves hide a long walk, and cutting it up would only add work
         LongParams lp = c->long_params;
@@ -865,17 +869,20 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
             const dim3 sgrid((n + RT_BLOCK - 1) / RT_BLOCK, c->n_lights);
             if (c->hscene.n_meshes == 0 && !(c->hscene.n_tlas != 0 && c->defer_from <= RT_MAX_LEVELS)) {
                 lp.budget_wave = 0;   // (no long-ray pass: nothing is walked as a packet)
-                hipLaunchKernelGGL(k_shadow_lanes<false>, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc);
+                hipLaunchKernelGGL(k_shadow_lanes<false>, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc, keys);
             } else {
                 auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc, long_shadow, lp); };
+                auto launch_area = [&](auto kern) { hipLaunchKernelGGL(kern, sgrid, block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc, long_shadow, lp, keys); };
                 const bool cnt = (c->count_visits & 2) != 0;
                 const bool rcp = c->rays_need_reciprocal;
                 if (lp.budget_wave) {
-                    if (cnt) launch(k_shadow<true, true>);
+                    if (c->has_area) { if (cnt) launch_area(k_shadow_area<true, true>); else launch_area(k_shadow_area<false, true>); }
+                    else if (cnt) launch(k_shadow<true, true>);
                     else if (rcp) launch(k_shadow<false, true>); else launch(k_shadow<false, true, false>);
                 } else {
                     main_variant = true;
-                    if (cnt) launch(k_shadow<true, false>);
+                    if (c->has_area) { if (cnt) launch_area(k_shadow_area<true, false>); else launch_area(k_shadow_area<false, false>); }
+                    else if (cnt) launch(k_shadow<true, false>);
                     else if (rcp) launch(k_shadow<false, false>); else launch(k_shadow<false, false, false>);
                 }
             }
@@ -883,15 +890,16 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
         HIP_TRY(c, hipEventRecord(W.ev[LW_SK], side));
         if (c->n_lights) {
             if (lp.budget_wave) {
-                if (c->count_visits & 2) hipLaunchKernelGGL(k_long_shadow<true>, dim3(RT_LONG_BLOCKS), block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc, long_shadow);
-                else hipLaunchKernelGGL(k_long_shadow<false>, dim3(RT_LONG_BLOCKS), block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc, long_shadow);
+                if (c->count_visits & 2) hipLaunchKernelGGL(k_long_shadow<true>, dim3(RT_LONG_BLOCKS), block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc, long_shadow, keys);
+                else hipLaunchKernelGGL(k_long_shadow<false>, dim3(RT_LONG_BLOCKS), block, 0, side, c->dscene, hitlist, hs, occ, n, dc, lc, long_shadow, keys);
             }
             n_sd++;
         }
         if (main_variant) { main_shadow[depth] = 1; n_main++; }
         HIP_TRY(c, hipEventRecord(W.ev[LW_S1], side));
         HIP_TRY(c, hipEventRecord(W.ev[LW_L0], side));
-        hipLaunchKernelGGL(k_light, grid, block, 0, side, c->dscene, c->levels[depth].lv, n, n_dev, occ, n);
+        if (c->has_area) hipLaunchKernelGGL(k_light_area, grid, block, 0, side, c->dscene, c->levels[depth].lv, n, n_dev, occ, n, dc);
+        else hipLaunchKernelGGL(k_light, grid, block, 0, side, c->dscene, c->levels[depth].lv, n, n_dev, occ, n);
         HIP_TRY(c, hipEventRecord(W.ev[LW_L1], side));
         n_tr++; n_sh++;
     }
@@ -1117,9 +1125,12 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     }
     // the shadow kernels take the light from the grid's y index
     if (d->n_lights > 65535u) return fail(c, RT_ERR_UNSUPPORTED, "more than 65535 lights");
+    uint64_t n_records = 0;      // one per sun and point light, one per sample of an area light (one for an area light without samples)
     for (uint32_t i = 0; i < d->n_lights; i++) {
-        if (d->lights[i].kind == RT_LIGHT_AREA) return fail(c, RT_ERR_UNSUPPORTED, "area lights draw from an unseeded RNG (lighting/area.rs:121) and are not rendered on the device");
         if (d->lights[i].kind > RT_LIGHT_AREA) return fail(c, RT_ERR_INVALID, "unknown light kind");
+        if (d->lights[i].kind == RT_LIGHT_AREA && d->lights[i].area_surface > RT_AREA_RECTANGLE) return fail(c, RT_ERR_INVALID, "unknown area light surface");
+        n_records += d->lights[i].kind == RT_LIGHT_AREA ? std::max<uint32_t>(1u, d->lights[i].area_iterations) : 1u;
+        if (n_records > 65535u) return fail(c, RT_ERR_UNSUPPORTED, "more than 65535 lights and area light samples");
     }
     for (uint32_t i = 0; i < d->n_materials; i++)
         if (d->materials[i].texture >= d->n_textures) return fail(c, RT_ERR_INVALID, "material: texture index out of range");
@@ -1309,16 +1320,31 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     if ((rc = upload(c, pln.data(), pln.size(), &H.planes)) != RT_OK) return rc;
     if ((rc = upload(c, bxs.data(), bxs.size(), &H.boxes)) != RT_OK) return rc;
 
-    std::vector<DLight> lights(d->n_lights);
+    std::vector<DLight> lights;
+    lights.reserve((size_t)n_records);
+    bool has_area = false;
     for (uint32_t i = 0; i < d->n_lights; i++) {
         const rt_light& l = d->lights[i];
-        DLight& dl = lights[i];
+        DLight dl;
         std::memset(&dl, 0, sizeof(dl));
-        dl.kind = l.kind; dl.specular_power = l.specular_power; dl.shadows = l.shadows;
+        dl.kind = l.kind == RT_LIGHT_SUN ? RT_DLIGHT_SUN : RT_DLIGHT_POINT;
+        dl.specular_power = l.specular_power; dl.shadows = l.shadows;
         for (int k = 0; k < 3; k++) { dl.col[k] = (double)l.color[k] / 255.; dl.v[k] = l.v[k]; }
         dl.intensity = l.intensity; dl.specular_strength = l.specular_strength;
         dl.shadow_coefficient = l.shadow_coefficient; dl.max_distance = l.max_distance;
+        if (l.kind != RT_LIGHT_AREA) { lights.push_back(dl); continue; }
+        // an area light: its samples' records in a row (area.rs:117: one point-light evaluation per iteration)
+        has_area = true;
+        dl.area_surface = l.area_surface; dl.area_n = l.area_iterations; dl.area_li = i; dl.area_radius = l.area_radius;
+        for (int q = 0; q < 4; q++) for (int k = 0; k < 3; k++) dl.area_corners[q][k] = l.area_corners[q][k];
+        if (l.area_iterations == 0) { dl.kind = RT_DLIGHT_AREA_EMPTY; lights.push_back(dl); continue; }
+        dl.kind = RT_DLIGHT_AREA_SAMPLE;
+        for (uint32_t it = 0; it < l.area_iterations; it++) { dl.area_it = it; lights.push_back(dl); }
     }
+    if (lights.size() != n_records) return fail(c, RT_ERR_INVALID, "light records miscounted");
+    H.n_lights = (uint32_t)lights.size();
+    H.has_area = has_area ? 1u : 0u; H.area_seed = c->area_seed;
+    c->has_area = has_area;
     if ((rc = upload(c, lights.data(), lights.size(), &H.lights)) != RT_OK) return rc;
 
     H.sky_kind = d->skybox.kind; H.sky_rgb = pack_rgb(d->skybox.color);
@@ -1336,6 +1362,17 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     for (uint32_t i = 0; i < d->n_meshes; i++) c->total_tris += d->meshes[i].n_tris;
     c->have_scene = true;
     c->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+int rt_set_area_seed(rt_ctx* c, uint64_t seed) {
+    if (!c) return RT_ERR_INVALID;
+    c->area_seed = seed;
+    if (c->have_scene) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        c->hscene.area_seed = seed;
+        HIP_TRY(c, hipMemcpy(reinterpret_cast<char*>(c->dscene) + offsetof(DScene, area_seed), &seed, sizeof(seed), hipMemcpyHostToDevice));
+    }
     return RT_OK;
 }
 

@@ -52,6 +52,10 @@ class Context:
         self.vw, self.vh = info["vw"], info["vh"]
         return self
 
+    def set_area_seed(self, seed=0x9E3779B97F4A7C15):
+        """rt_set_area_seed: the seed of the area lights' sample points (the default is the oracle's default too)"""
+        self._check(N.gpu().rt_set_area_seed(self._c, C.c_uint64(seed)))
+
     def render(self, ids=False):
         """rt_render -> (rgb (vh, vw, 3) u8, ids (vh, vw, 2) u32 or None, RtStats)"""
         rgb = np.empty((self.vh, self.vw, 3), dtype=np.uint8)

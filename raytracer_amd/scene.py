@@ -224,7 +224,7 @@ class Point:
 
 
 class Area:
-    """lighting/area.rs:55-95 (CPU path only: its sampling draws from an unseeded RNG)"""
+    """lighting/area.rs:55-95 (its sample points come from a seeded counter-based generator here, from an unseeded one there)"""
 
     def __init__(self, surface="sphere", position=(0., 0., 0.), radius=0., corners=None, color=(255, 255, 255),
                  intensity=6., specular_power=32, specular_strength=0.7, iterations=4, max_distance=50.):

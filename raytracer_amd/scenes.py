@@ -103,7 +103,7 @@ def refraction_scene(vw=1920, vh=1080, cubemap=None):
 
 
 def cornell_scene(vw=1920, vh=1080, glass_ior=1.5, icosphere_order=None):
-    """scenes/cornell.sdl (config 1; has an area light => CPU path only); glass_ior: the first sphere's index of
+    """scenes/cornell.sdl (config 1); glass_ior: the first sphere's index of
     refraction, the language's default unless a test wants another picture.  icosphere_order: the box's contents are
     those of scenes/cornell_icosahedron.sdl instead -- the icosphere of that many subdivisions (the file says 3), scale
     0.5 at <0.3, -0.5, -0.5>"""
@@ -236,16 +236,21 @@ def terrain_scene(vw=7680, vh=4320, w=72, h=72, seed=11, cubemap=None):
     return s
 
 
-def small_mixed_scene(vw=160, vh=120, cells=24, seed=5, device_bvh=False):
+def small_mixed_scene(vw=160, vh=120, cells=24, seed=5, device_bvh=False, area_lights=False):
     """A small scene touching every device code path: mesh (reflective), glass
     sphere (refraction + fresnel mix), see-through box (ior 1), checker plane,
-    emissive box, sun + two point lights, cubemap skybox."""
+    emissive box, sun + two point lights, cubemap skybox.  area_lights: also a spherical area light whose reach ends
+    inside the scene (some hits see some of its sample points beyond max_distance, area.rs:126-128) and a rectangular
+    one."""
     s = Scene()
     s.set_camera(Camera(vw=vw, vh=vh, origin=(0.3, 2.5, 9.), yaw=0.05, pitch=-0.2, fov=60.))
     s.skybox_cubemap(procedural_cubemap(32, seed=seed))
     s.add_light(sdl_sun((-0.6, -1., -0.3)))
     s.add_light(Point(position=(3., 4., 2.), intensity=8.))
     s.add_light(Point(position=(-4., 3., 1.), intensity=5., color=(255, 200, 160)))
+    if area_lights:
+        s.add_light(Area(surface="sphere", position=(1., 4., 3.), radius=0.9, iterations=5, intensity=5., max_distance=6.5, color=(200, 220, 255)))
+        s.add_light(Area(surface="rectangle", corners=[(-3., 5., -1.), (-3., 5., 1.), (-1., 5., -1.), (-1., 5.5, 1.)], iterations=3, intensity=3.))
     mesh = Mesh.heightfield(cells, cells, cell=0.5, amplitude=0.6, base_freq=0.3, octaves=3, seed=seed,
                             material=sdl_material(Texture.solid((180, 200, 160)), reflectiveness=0.3))
     sdl_mesh(mesh, position=(0., -0.5, 0.), device_bvh=device_bvh)

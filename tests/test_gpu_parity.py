@@ -293,7 +293,8 @@ def test_scene_render_through_host_api(tmp_path):
 
 
 def test_errors(gpu_ctx):
-    s = scenes.cornell_scene(32, 32)                                     # area light: not on the device
+    s = scenes.loop_scene(32, 24)                                         # more light records than a launch has rows
+    s.add_light(ra.Area(surface="sphere", position=(0., 3., 0.), radius=1., iterations=70000))
     with pytest.raises(N.RtError) as e:
         gpu_ctx.upload(s)
     assert e.value.code == N.RT_ERR_UNSUPPORTED
@@ -786,3 +787,73 @@ def test_shared_reciprocal_divisions_equal_the_plain_ones():
     assert all(l.rstrip().endswith(" 0 differ") for l in lines), out.stdout
     # the fast path is what ran: every vector of the narrow sweeps, almost none of the widest
     assert "100.0 % through the shared reciprocal" in lines[0] and " 0.8 % through the shared reciprocal" in lines[6]
+
+
+def _area_frames(gpu_ctx, s, seed):
+    try:
+        if seed is None:
+            oracle.set_area_seed(); gpu_ctx.set_area_seed()
+        else:
+            oracle.set_area_seed(seed); gpu_ctx.set_area_seed(seed)
+        rgb, ids, st = gpu_ctx.render(ids=True)
+        o_rgb, o_ids, o_st, oc = oracle.render(s, 0)
+    finally:
+        oracle.set_area_seed(); gpu_ctx.set_area_seed()
+    assert oc.would_panic == 0
+    return rgb, ids, st, o_rgb, o_ids, o_st
+
+
+@pytest.mark.parametrize("seed", [None, 20211122])
+def test_area_lights_equal_the_oracle(gpu_ctx, seed):
+    """lighting/area.rs:114-166 on the device: every sample point is a function of (seed, pixel, the ray's place in
+    the pixel's tree of rays, light, sample), the same in the oracle, so the frames are equal byte for byte and the
+    ray counts agree -- also where a sample lies beyond max_distance and ends its light's loop (area.rs:126-128)."""
+    s = scenes.small_mixed_scene(200, 120, cells=8, area_lights=True)
+    gpu_ctx.upload(s)
+    rgb, ids, st, o_rgb, o_ids, o_st = _area_frames(gpu_ctx, s, seed)
+    assert np.array_equal(rgb, o_rgb) and np.array_equal(ids, o_ids)
+    assert ray_counts(st) == ray_counts(o_st)
+    assert list(st.rays_per_level) == list(o_st.rays_per_level)
+    # the area lights matter to the picture, and the seed to the area lights
+    gpu_ctx.upload(scenes.small_mixed_scene(200, 120, cells=8))
+    assert not np.array_equal(gpu_ctx.render()[0], rgb)
+    gpu_ctx.upload(s)
+    try:
+        gpu_ctx.set_area_seed(7)
+        assert not np.array_equal(gpu_ctx.render()[0], rgb)
+        gpu_ctx.set_area_seed(*(() if seed is None else (seed,)))
+        assert np.array_equal(gpu_ctx.render()[0], rgb)
+    finally:
+        gpu_ctx.set_area_seed()
+
+
+@pytest.mark.parametrize("order", [None, 2])
+def test_cornell_box_equals_the_oracle(gpu_ctx, order):
+    """scenes/cornell.sdl and scenes/cornell_icosahedron.sdl (README.md:454-462): a rectangular area light of 64
+    samples over a glass sphere, or an icosphere mesh"""
+    s = scenes.cornell_scene(160, 160, icosphere_order=order)
+    gpu_ctx.upload(s)
+    rgb, ids, st, o_rgb, o_ids, o_st = _area_frames(gpu_ctx, s, None)
+    assert np.array_equal(rgb, o_rgb) and np.array_equal(ids, o_ids)
+    assert ray_counts(st) == ray_counts(o_st)
+    # shards and sets of frames see the same sample points: a pixel's key does not depend on where it is rendered
+    import torch
+    vw, vh = gpu_ctx.vw, gpu_ctx.vh
+    r = rd.ShardedRenderer(gpu_ctx, 1, 3, torch.device("cuda:0"), batch=2)
+    r.render_local(2)
+    idx = rd.shard_pixel_indices(vw, vh, 1, 3)
+    got = r.local.cpu().numpy().reshape(2, r.slots, 3)
+    for f in range(2):
+        part = got[f][: len(idx)]
+        assert np.array_equal(part[idx >= 0], rgb.reshape(-1, 3)[idx[idx >= 0]])
+
+
+def test_area_light_without_samples(gpu_ctx):
+    """iterations 0: the sums of area.rs:161-165 are 0 / 0, and every lit pixel turns black (material.rs:38-44 casts NaN to 0)"""
+    s = scenes.loop_scene(96, 64)
+    s.add_light(ra.Area(surface="sphere", position=(0., 3., 0.), radius=1., iterations=0))
+    gpu_ctx.upload(s)
+    rgb, ids, st = gpu_ctx.render(ids=True)
+    o_rgb, o_ids, o_st, oc = oracle.render(s, 0)
+    assert np.array_equal(rgb, o_rgb) and ray_counts(st) == ray_counts(o_st)
+    assert (rgb[ids[..., 0] != N.RT_ID_NONE] == 0).all()

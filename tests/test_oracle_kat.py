@@ -410,7 +410,7 @@ def _assert_a_draw_from_the_ensemble(golden, held_out, mu, scale, fixed, regions
         assert abs(zm) < 0.02 and abs(hm) < 0.02, (name, zm, hm)            # no bias in either direction
         assert abs(zs - hs) < 0.15 and 0.8 < zs < 1.2, (name, zs, hs)
         assert tail < 2 * htail + 0.001, (name, tail, htail)
-        assert same >= hsame - 0.015 and same >= 0.92, (name, same, hsame)   # not 1: a few seeds leave some values fixed by chance
+        assert same >= hsame - 0.015 and same >= 0.9, (name, same, hsame)    # not 1: a few seeds leave some values fixed by chance (a further oracle render scores 0.92-0.99)
 
 
 def test_golden_cornell_box_in_distribution():
