@@ -87,3 +87,12 @@ def test_hot_kernels_keep_their_waves_per_simd(tmp_path):
     assert light["scratch"] == 0 and waves_per_simd(light) == 8
     spawn = [v for k, v in md.items() if k.startswith("_Z7k_spawnILb0ELb0EE")]
     assert len(spawn) == 1 and spawn[0]["scratch"] == 0 and waves_per_simd(spawn[0]) >= 6
+    # the kernels of scenes with area lights are kernels of their own (the others are what they were without them);
+    # they keep the shadow packets' waves, and nothing of theirs spills
+    area = {k: v for k, v in md.items() if k.startswith("_Z13k_shadow_areaILb0E") or k.startswith("_Z12k_light_area")}
+    assert len(area) == 3, sorted(area)
+    for k, v in area.items():
+        # (the variant with a step budget, for small launches only, keeps three values in scratch memory)
+        assert v["scratch"] <= (16 if "areaILb0ELb1E" in k else 0), (k, v)
+        if "shadow" in k:
+            assert v["lds"] <= 18 * 1280 and waves_per_simd(v) == 7, (k, v)

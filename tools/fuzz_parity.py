@@ -1,7 +1,9 @@
 """Random scenes, GPU frame against the CPU checker: colours, primary ids and ray counts must be identical.
 
 usage: fuzz_parity.py [n_scenes] [first_seed]      (FUZZ_RICH=1: image textures, larger meshes, more objects;
-                                                    FUZZ_SHARDS=1: every frame also rendered as 2-9 shards and reassembled)
+                                                    FUZZ_SHARDS=1: every frame also rendered as 2-9 shards and reassembled;
+                                                    FUZZ_AREA=1: 1-2 area lights per scene, spheres and rectangles of 0-9 sample
+                                                    points with short and long reach, and a seed of its own per scene)
 Every scene draws its own mix of objects (0-40 spheres and boxes, so both the linear object list and the object tree
 occur; 0-2 planes; 0-2 height-field meshes, some see-through with ior 1, some refracting), materials, lights (suns
 with and without shadows, point lights with short and long reach), skybox kind, ray depth, camera and frame size
@@ -32,7 +34,18 @@ def random_material(rng, allow_far=True, rich=False):
     return scenes.sdl_material(tex, reflectiveness=refl, transparency=transp, ior=ior, emissivity=emis)
 
 
-def random_scene(seed, rich=False):
+def random_area_light(rng):
+    common = dict(iterations=int(rng.choice([0, 1, 2, 3, 4, 4, 5, 9])), intensity=float(rng.uniform(1, 12)),
+                  max_distance=float(rng.choice([3., 6., 10., 50.])), color=tuple(int(x) for x in rng.integers(100, 256, 3)))
+    centre = np.array([rng.uniform(-5, 5), rng.uniform(1, 7), rng.uniform(-5, 5)])
+    if rng.integers(0, 2):
+        return ra.Area(surface="sphere", position=tuple(float(x) for x in centre), radius=float(rng.uniform(0., 1.5)), **common)
+    a, b = rng.uniform(-1.5, 1.5, 3), rng.uniform(-1.5, 1.5, 3)
+    corners = [centre, centre + a, centre + b, centre + a + b + rng.uniform(-0.2, 0.2, 3)]     # (not quite a parallelogram)
+    return ra.Area(surface="rectangle", corners=[tuple(float(x) for x in c) for c in corners], **common)
+
+
+def random_scene(seed, rich=False, area=False):
     """rich: image textures on planes, boxes and meshes (not on spheres, whose texture coordinates go through
     atan2/asin and may differ in the last bit between the two libms), larger meshes, more objects"""
     rng = np.random.default_rng(seed)
@@ -55,6 +68,10 @@ def random_scene(seed, rich=False):
         s.add_light(ra.Point(position=tuple(float(x) for x in (rng.uniform(-5, 5), rng.uniform(1, 7), rng.uniform(-5, 5))),
                              intensity=float(rng.uniform(2, 20)), max_distance=float(rng.choice([3., 10., 50.])),
                              color=tuple(int(x) for x in rng.integers(100, 256, 3))))
+    if area:
+        arng = np.random.default_rng([seed, 0xA5EA])     # (a stream of its own: the other draws stay what they are without area lights)
+        for _ in range(int(arng.integers(1, 3))):
+            s.add_light(random_area_light(arng))
     for _ in range(int(rng.integers(0, 3))):
         cells = int(rng.integers(1, 60 if rich else 20))
         mesh = ra.Mesh.heightfield(cells, cells, cell=float(rng.uniform(0.3, 1.0)), amplitude=float(rng.uniform(0., 1.5)),
@@ -81,10 +98,14 @@ def main():
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     rich = bool(int(os.environ.get("FUZZ_RICH", "0")))
     shards = bool(int(os.environ.get("FUZZ_SHARDS", "0")))
+    area = bool(int(os.environ.get("FUZZ_AREA", "0")))
     bad = 0
     with ra.Context(0) as ctx:
         for seed in range(first, first + n):
-            s, (vw, vh) = random_scene(seed, rich)
+            s, (vw, vh) = random_scene(seed, rich, area)
+            if area:
+                area_seed = (seed * 0x9E3779B97F4A7C15 + 12345) & 0xFFFFFFFFFFFFFFFF
+                oracle.set_area_seed(area_seed); ctx.set_area_seed(area_seed)
             ctx.upload(s)
             rgb, ids, st = ctx.render(ids=True)
             if shards:
