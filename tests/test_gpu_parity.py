@@ -473,6 +473,29 @@ def test_sdl_script_renders_like_the_oracle(gpu_ctx):
     assert oc.would_panic == 0
 
 
+def test_sdl_script_with_area_lights(gpu_ctx):
+    """area_light objects of the scene description language (interpret.rs:976-1035: a sphere and a rectangle) on the GPU"""
+    src = """
+        camera { vw: 128, vh: 96, origin: <0, 1.5, 6>, pitch: -0.15, fov: 65 }
+        scene { max_ray_depth: 2, ambient: gray(20) }
+        skybox { type: "solid", color: gray(10) }
+        area_light { surface: "sphere", position: <2, 3, 1>, radius: 0.6, iterations: 6, intensity: 5 }
+        area_light { surface: "rectangle", c00: <-2, 3, -1>, c01: <-2, 3, 1>, c10: <-1, 3, -1>, c11: <-1, 3, 1>,
+                     iterations: 4, intensity: 3, max_distance: 4.5, color: rgb(255, 220, 180) }
+        plane { origin: <0, 0, 0>, material: { texture: checkerboard(gray(220), gray(90)), reflectiveness: 0.2 } }
+        sphere { position: <0, 1, -1>, radius: 1, material: { transparency: 0.6, reflectiveness: 0.4 } }
+        aabb { position: <1.5, 0.4, 1>, size: <0.4, 0.4, 0.4>, material: { texture: solid(rgb(60, 120, 240)) } }
+    """
+    s = ra.SdlScene(src)
+    assert (s.n_objects, s.n_lights) == (3, 2)
+    gpu_ctx.upload(s)
+    rgb, ids, st = gpu_ctx.render(ids=True)
+    o_rgb, o_ids, o_st, oc = oracle.render(s, 0)
+    assert np.array_equal(rgb, o_rgb) and np.array_equal(ids, o_ids)
+    assert ray_counts(st) == ray_counts(o_st) and oc.would_panic == 0
+    assert st.rays_shadow > 4 * st.rays_primary                 # (up to ten samples per lit hit, less those out of reach)
+
+
 def _spine_mesh(levels, seed=9):
     """A mesh under a hand-built, deliberately lopsided tree: spine node i holds a pair of large triangles (its first
     child, two leaves, the larger box) and the rest of the spine (its second child).  The four-wide device tree then
