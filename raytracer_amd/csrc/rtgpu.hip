@@ -42,7 +42,7 @@ struct LevelWork {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // see LW_*
 };
 enum { LW_T0, LW_T1, LW_P, LW_S0, LW_SK, LW_S1, LW_L0, LW_L1 };
-#define RT_MAX_LEVELS 9   /* trace_ray depths 0..max_ray_depth (at most 7), and one more for the counters' sake */
+#define RT_MAX_LEVELS 33  /* trace_ray depths 0..max_ray_depth (at most 31; the reference's own scenes go up to 8, scenes/fedora_light.sdl:6), and one more for the counters' sake */
 #define RT_SIDE_STREAMS 4
 
 }  // namespace
@@ -759,10 +759,11 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
     hipStream_t s = c->stream;
     int rc;
     const size_t n_lc = (size_t)c->max_depth + 2;
-    if (n_lc > RT_MAX_LEVELS) return fail(c, RT_ERR_UNSUPPORTED, "max_ray_depth above 7 is not supported");
+    if (n_lc > RT_MAX_LEVELS) return fail(c, RT_ERR_UNSUPPORTED, "max_ray_depth above 31 is not supported");
     if ((rc = ensure_level_counts(c, n_lc)) != RT_OK) return rc;
-    std::memset(c->hcounters, 0, RT_MAX_LEVELS * sizeof(DCounters));
-    HIP_TRY(c, hipMemsetAsync(c->dcounters, 0, RT_MAX_LEVELS * sizeof(DCounters), s));
+    // (only the counters of the levels this scene can have are cleared, copied back and summed)
+    std::memset(c->hcounters, 0, n_lc * sizeof(DCounters));
+    HIP_TRY(c, hipMemsetAsync(c->dcounters, 0, n_lc * sizeof(DCounters), s));
     HIP_TRY(c, hipMemsetAsync(c->d_lcounts, 0, n_lc * sizeof(DLevelCounts), s));
 
     // room per level: exact for level 0; measured frames learn the others as they go
@@ -915,7 +916,7 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
                            c->levels[depth + 1].lv, n, n_dev, depth == 0 ? 1 : 0, d_rgb, map);
     }
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
-    HIP_TRY(c, hipMemcpyAsync(c->hcounters, c->dcounters, RT_MAX_LEVELS * sizeof(DCounters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->hcounters, c->dcounters, n_lc * sizeof(DCounters), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(c->h_lcounts, c->d_lcounts, n_lc * sizeof(DLevelCounts), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
@@ -945,7 +946,7 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
     }
     (void)hipEventElapsedTime(&ms_resolve, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&ms_all, c->ev[0], c->ev[2]);
-    for (size_t d = 0; d < RT_MAX_LEVELS; d++)
+    for (size_t d = 0; d < n_lc; d++)
         for (int k = 0; k < RT_SHARDS; k++) {
             const DShard& sh = c->hcounters[d].shard[k];
             stats.rays_reflect += sh.rays_reflect; stats.rays_transmit += sh.rays_transmit; stats.rays_shadow += sh.rays_shadow;
@@ -1113,7 +1114,7 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     free_scene(c);
     if (d->camera.vw <= 0 || d->camera.vh <= 0) return fail(c, RT_ERR_INVALID, "camera: vw and vh must be positive");
     if ((uint64_t)d->camera.vw * (uint64_t)d->camera.vh >= 0x7FFFFFFFull) return fail(c, RT_ERR_UNSUPPORTED, "frame larger than 2^31 pixels");
-    if (d->options.max_ray_depth > 7) return fail(c, RT_ERR_UNSUPPORTED, "max_ray_depth above 7 is not supported");
+    if (d->options.max_ray_depth + 2ull > RT_MAX_LEVELS) return fail(c, RT_ERR_UNSUPPORTED, "max_ray_depth above 31 is not supported");
     {
         // every array the description names is dereferenced below: a count without an array is refused here
         const struct { const void* p; uint32_t n; const char* what; } arrays[] = {

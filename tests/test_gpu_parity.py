@@ -121,6 +121,39 @@ def test_empty_scene_and_options(gpu_ctx):
     assert np.array_equal(rgb, o[0]) and ray_counts(st) == ray_counts(o[2])
 
 
+def test_ray_depths_beyond_eight(gpu_ctx):
+    """max_ray_depth is a u32 in the reference (scene.rs:19) and its own scenes go up to 8 (scenes/fedora_light.sdl:6):
+    the device takes depths up to 31, one wavefront level per depth"""
+    s = ra.Scene()
+    s.set_camera(ra.Camera(vw=96, vh=64, origin=(0., 1., 5.), pitch=0.05, yaw=0.01))
+    s.skybox_normal()
+    s.add_light(scenes.sdl_sun((-0.3, -1., -0.4)))
+    s.add_light(ra.Point(position=(0., 1., 1.), intensity=6.))
+    mirror = scenes.sdl_material(ra.Texture.checkerboard((250, 250, 250), (120, 160, 200)), reflectiveness=0.9)
+    s.add(scenes.sdl_plane((0., -1., 0.), (0., 1., 0.), mirror))        # a corridor between two mirrors
+    s.add(scenes.sdl_plane((0., 3., 0.), (0., -1., 0.), mirror))
+    s.add(ra.Sphere((0.5, 0.5, -1.), 0.8, scenes.sdl_material(ra.Texture.solid((255, 90, 60)), reflectiveness=0.5)))
+    for depth in (8, 20, 31):
+        s.set_options(max_ray_depth=depth)
+        gpu_ctx.upload(s)
+        rgb, ids, st = gpu_ctx.render(ids=True)
+        o_rgb, o_ids, o_st, oc = oracle.render(s, 0)
+        assert np.array_equal(rgb, o_rgb) and np.array_equal(ids, o_ids) and oc.would_panic == 0
+        assert ray_counts(st) == ray_counts(o_st) and list(st.rays_per_level) == list(o_st.rays_per_level)
+        assert st.rays_per_level[7] > 1000 and st.rays_reflect > (depth - 2) * 1000     # the corridor is used to its end
+    s.set_options(max_ray_depth=32)
+    with pytest.raises(N.RtError) as e:
+        gpu_ctx.upload(s)
+    assert e.value.code == N.RT_ERR_UNSUPPORTED
+    # two children per hit (glass), nine levels deep
+    s = scenes.refraction_scene(96, 54)
+    s.set_options(max_ray_depth=9)
+    gpu_ctx.upload(s)
+    rgb, ids, st = gpu_ctx.render()
+    o = oracle.render(s, 0)
+    assert np.array_equal(rgb, o[0]) and ray_counts(st) == ray_counts(o[2])
+
+
 def test_transparent_mesh_and_single_triangle(gpu_ctx):
     """meshes that need Hit::far: see-through (ior 1) and refracting (ior 1.5) materials (scene.rs:133-161)"""
     for ior in (1.0, 1.5):
