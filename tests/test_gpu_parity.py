@@ -904,6 +904,30 @@ def test_cornell_box_equals_the_oracle(gpu_ctx, order):
         assert np.array_equal(part[idx >= 0], rgb.reshape(-1, 3)[idx[idx >= 0]])
 
 
+@pytest.mark.parametrize("image,order", [("readme_11_22_2021_5.png", None), ("readme_11_22_2021_7.png", 3), ("readme_11_22_2021_6.png", 0)])
+def test_device_cornell_boxes_are_draws_from_the_distribution_of_the_reference_authors_renders(gpu_ctx, image, order):
+    """images/readme/11_22_2021_{5,6,7}.png against the device's own renders, without the oracle in between: the
+    reference draws the area light's sample points from an unseeded generator, so the question is whether the author's
+    image is one more draw from the distribution of the device's frames over seeds (tests/test_oracle_kat.py asks the
+    same of the oracle and explains the measure)"""
+    import test_oracle_kat as K
+    golden = ra.read_png(os.path.join(GOLDEN, image)).astype(np.float64)
+    s = scenes.cornell_scene(512, 512, icosphere_order=order)
+    gpu_ctx.upload(s)
+
+    def frame_of(seed):
+        gpu_ctx.set_area_seed(seed)
+        return gpu_ctx.render(ids=True)[:2]
+
+    try:
+        mu, scale, fixed, ids, held_out = K._ensemble(s, 6, frame_of)
+    finally:
+        gpu_ctx.set_area_seed()
+    contents = np.repeat((ids[..., 0] == 6)[..., None], 3, axis=2)     # the glass sphere / the icosphere
+    assert contents.sum() > 3 * 15000
+    K._assert_a_draw_from_the_ensemble(golden, held_out, mu, scale, fixed, (("frame", np.ones_like(fixed)), ("contents", contents)))
+
+
 def test_area_light_without_samples(gpu_ctx):
     """iterations 0: the sums of area.rs:161-165 are 0 / 0, and every lit pixel turns black (material.rs:38-44 casts NaN to 0)"""
     s = scenes.loop_scene(96, 64)

@@ -374,18 +374,19 @@ def test_golden_readme_10_7_scene():
     assert (np.abs(rgb2.astype(int) - golden.reshape(-1, 3)[px].astype(int)).max(axis=1) > 1).mean() > 0.3
 
 
-def _ensemble(scene, n_seeds):
-    """-> per-value mean and spread of n_seeds oracle renders with different area-light seeds, the mask of the values no
+def _ensemble(scene, n_seeds, frame_of=None):
+    """-> per-value mean and spread of n_seeds renders with different area-light seeds, the mask of the values no
     seed moved, the primary object ids, and one further render with yet another seed (what a draw from the same
-    distribution looks like)"""
+    distribution looks like).  frame_of(seed) -> (rgb, ids): the renderer; default: the oracle"""
+    def oracle_frame(seed):
+        oracle.set_area_seed(seed)
+        return oracle.render(scene, 0)[:2]
     try:
         frames = []
         for k in range(n_seeds):
-            oracle.set_area_seed(1000 + 7919 * k)
-            rgb, ids, st, oc = oracle.render(scene, 0)
+            rgb, ids = (frame_of or oracle_frame)(1000 + 7919 * k)
             frames.append(rgb.astype(np.float64))
-        oracle.set_area_seed(424242)
-        held_out = oracle.render(scene, 0, ids=False)[0].astype(np.float64)
+        held_out = (frame_of or oracle_frame)(424242)[0].astype(np.float64)
     finally:
         oracle.set_area_seed()
     e = np.stack(frames)
