@@ -101,6 +101,9 @@ struct rt_ctx {
     DCounters* dcounters = nullptr;   // [RT_MAX_LEVELS], one set per trace_ray depth
     DCounters* hcounters = nullptr;   // pinned
     void* d_out = nullptr; size_t d_out_cap = 0;      // rgb staging for rt_render
+    void* h_stage = nullptr; size_t h_stage_cap = 0;  // pinned host staging for rt_render's copy of the frame (copy_frame_to_host)
+    std::vector<hipEvent_t> stage_ev;                 // one per chunk of that copy
+    uint32_t copy_threads = 4;                        // RTGPU_COPY_THREADS: host threads that move the chunks on (0: one plain hipMemcpy)
     void* d_ids = nullptr; size_t d_ids_cap = 0;      // compact ids
     void* d_ids2 = nullptr; size_t d_ids2_cap = 0;    // row-major ids
     void* d_cams = nullptr; size_t d_cams_cap = 0;    // cameras of a batch of frames (rt_render_shard_batch)
@@ -1028,6 +1031,7 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         if (const char* b = std::getenv("RTGPU_BUDGET_WAVE")) c->long_params.budget_wave = (uint32_t)std::strtoul(b, nullptr, 10);
         c->serial = std::getenv("RTGPU_SERIAL") != nullptr;
         if (const char* b = std::getenv("RTGPU_SYNC_LEVELS")) c->sync_levels = std::strtol(b, nullptr, 10) != 0;
+        if (const char* b = std::getenv("RTGPU_COPY_THREADS")) c->copy_threads = (uint32_t)std::min<unsigned long>(std::strtoul(b, nullptr, 10), 16ul);
         if (const char* b = std::getenv("RTGPU_PACKET_DEPTH")) c->packet_depth = (uint32_t)std::strtoul(b, nullptr, 10);
         if (const char* b = std::getenv("RTGPU_DEFER_FROM")) { c->defer_from = (uint32_t)std::strtoul(b, nullptr, 10); c->defer_from_set = true; }
         if (const char* b = std::getenv("RTGPU_DEFER_SMALL")) c->defer_small = b[0] != '0';
@@ -1082,6 +1086,8 @@ void rt_ctx_destroy(rt_ctx* c) {
     if (c->h_lcounts) (void)hipHostFree(c->h_lcounts);
     for (auto ss : c->side) if (ss) (void)hipStreamDestroy(ss);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (auto ev : c->stage_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->d_ids) (void)hipFree(c->d_ids);
     if (c->d_ids2) (void)hipFree(c->d_ids2);
     if (c->d_cams) (void)hipFree(c->d_cams);
@@ -1366,6 +1372,54 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     return RT_OK;
 }
 
+// A finished frame from device memory into the caller's (pageable) buffer, after whatever is queued on the context's
+// stream.  hipMemcpy into pageable memory stages through pinned memory chunk by chunk with one host thread behind it
+// (about 18 GB/s here, less into pages the caller has never touched); this does the same with the staging buffer its
+// own and several threads moving the chunks on as they land, so that the copy runs at the link's rate.  Returns with
+// the bytes in place and the stream idle.
+static int copy_frame_to_host(rt_ctx* c, void* dst, const void* d_src, size_t bytes) {
+    const size_t CHUNK = (size_t)1 << 20;
+    if (c->copy_threads == 0 || bytes < 4 * CHUNK) {
+        HIP_TRY(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return RT_OK;
+    }
+    if (c->h_stage_cap < bytes) {
+        if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_cap = 0; }
+        if (hipHostMalloc(&c->h_stage, bytes, hipHostMallocDefault) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipHostMalloc failed for the frame's staging buffer");
+        c->h_stage_cap = bytes;
+    }
+    const size_t n_chunks = (bytes + CHUNK - 1) / CHUNK;
+    while (c->stage_ev.size() < n_chunks) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->stage_ev.push_back(e);
+    }
+    char* stage = static_cast<char*>(c->h_stage);
+    for (size_t k = 0; k < n_chunks; k++) {
+        const size_t off = k * CHUNK, len = std::min(CHUNK, bytes - off);
+        HIP_TRY(c, hipMemcpyAsync(stage + off, static_cast<const char*>(d_src) + off, len, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipEventRecord(c->stage_ev[k], c->stream));
+    }
+    const uint32_t n_thr = (uint32_t)std::min<size_t>(c->copy_threads, n_chunks);
+    std::atomic<int> bad{0};
+    auto mover = [&](uint32_t t) {
+        if (hipSetDevice(c->device) != hipSuccess) { bad = 1; return; }
+        for (size_t k = t; k < n_chunks; k += n_thr) {
+            if (hipEventSynchronize(c->stage_ev[k]) != hipSuccess) { bad = 1; return; }
+            const size_t off = k * CHUNK, len = std::min(CHUNK, bytes - off);
+            std::memcpy(static_cast<char*>(dst) + off, stage + off, len);
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < n_thr; t++) th.emplace_back(mover, t);
+    mover(0);
+    for (auto& x : th) x.join();
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (bad) return fail(c, RT_ERR_DEVICE, "copying the frame to host memory failed");
+    return RT_OK;
+}
+
 int rt_set_area_seed(rt_ctx* c, uint64_t seed) {
     if (!c) return RT_ERR_INVALID;
     c->area_seed = seed;
@@ -1394,14 +1448,13 @@ int rt_render(rt_ctx* c, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* stat
     rt_stats st;
     rc = render_frame(c, 0, 1, 1, static_cast<uint8_t*>(c->d_out), prim_id_out ? static_cast<uint32_t*>(c->d_ids) : nullptr, &st);
     if (rc != RT_OK) return rc;
-    HIP_TRY(c, hipMemcpyAsync(rgb_out, c->d_out, px * 3, hipMemcpyDeviceToHost, c->stream));
     if (prim_id_out) {
         ShardMap map = make_map(c->vw, c->vh, 0, 1, 1);
         hipLaunchKernelGGL(k_ids_rowmajor, dim3(((uint32_t)slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->dscene,
                            static_cast<const uint32_t*>(c->d_ids), static_cast<uint32_t*>(c->d_ids2), (uint32_t)slots, map);
         HIP_TRY(c, hipMemcpyAsync(prim_id_out, c->d_ids2, px * 8, hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((rc = copy_frame_to_host(c, rgb_out, c->d_out, px * 3)) != RT_OK) return rc;
     HIP_TRY(c, hipGetLastError());
     st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     st.device_bytes = c->scene_bytes + c->work_bytes;
