@@ -74,8 +74,36 @@ def test_area_light_runs_and_is_repeatable():
     s = scenes.cornell_scene(48, 48)
     a = oracle.render(s, 3)
     b = oracle.render(s, 1)
-    assert np.array_equal(a[0], b[0])                                       # the seeded stand-in RNG is per pixel
+    assert np.array_equal(a[0], b[0])                                       # the seeded stand-in generator does not depend on the thread
     assert a[2].rays_shadow > 48 * 48                                       # 64 samples per hit (cornell.sdl:29)
+    # a sample point is a function of (seed, pixel, place in the pixel's tree of rays, light, sample): any subset of
+    # the pixels, in any order, gets the points the whole frame gets; another seed gives another frame
+    px = np.random.default_rng(1).permutation(48 * 48)[:500].astype(np.uint32)
+    sub = oracle.render(s, 2, pixels=px)
+    assert np.array_equal(sub[0], a[0].reshape(-1, 3)[px])
+    try:
+        oracle.set_area_seed(99)
+        c = oracle.render(s, 0)
+    finally:
+        oracle.set_area_seed()
+    assert not np.array_equal(c[0], a[0]) and c[2].rays_shadow == a[2].rays_shadow
+    assert np.array_equal(oracle.render(s, 0)[0], a[0])
+
+
+def test_area_light_reach_and_empty_sample_list():
+    """area.rs:126-128: the first sample beyond max_distance ends the light's loop with LightShading::default(), and the
+    samples before it have cast their rays; area.rs:161-165 with no samples: 0 / 0, every lit pixel black"""
+    s = scenes.small_mixed_scene(64, 48, cells=6, area_lights=True)
+    full = oracle.render(s, 0)
+    plain = oracle.render(scenes.small_mixed_scene(64, 48, cells=6), 0)
+    lit_hits = plain[2].rays_shadow // 3                                     # sun + two point lights: three casts per lit hit
+    extra = full[2].rays_shadow - plain[2].rays_shadow
+    assert 0 < extra < lit_hits * (5 + 3)                                   # fewer than 5 + 3 per lit hit: some loops ended early
+    assert extra > lit_hits * 3 // 2                                         # ... but the rectangle's three are always in reach
+    e = scenes.loop_scene(48, 32)
+    e.add_light(ra.Area(surface="sphere", position=(0., 3., 0.), radius=1., iterations=0))
+    rgb, ids, st, oc = oracle.render(e, 0)
+    assert (rgb[ids[..., 0] != 0xFFFFFFFF] == 0).all() and st.rays_shadow == oracle.render(scenes.loop_scene(48, 32), 0)[2].rays_shadow
 
 
 def test_emissive_surface_ignores_lighting():
