@@ -353,8 +353,12 @@ def main():
                         k = inp["k_shadow_main"]
                         traffic = k["hbm_bytes_per_launch"]
                         fr["hbm"] = {"achieved": traffic / dur / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_launch": traffic,
-                                     "note": "(2 x FETCH_SIZE + WRITE_SIZE) of the counter passes in profiles/, per launch"}
+                                     "note": "(2 x FETCH_SIZE + WRITE_SIZE) of the counter passes in profiles/, per launch; an upper bound: the counter tallies vector-memory fetches at half and fetches through the scalar cache exactly (profiles/r2_fetch_calibration.json)"}
                         fr["hbm"]["frac"] = fr["hbm"]["achieved"] / HBM_PEAK_GBS
+                        if "fetch_size_raw_bytes_per_launch" in k:
+                            low = k["fetch_size_raw_bytes_per_launch"] + k.get("write_bytes_per_launch", 0)
+                            fr["hbm"]["per_launch_lower_bound"] = low               # FETCH_SIZE as it reads + WRITE_SIZE
+                            fr["hbm"]["frac_lower_bound"] = low / dur / 1e9 / HBM_PEAK_GBS
                         busy = k["valu_busy_cycles_per_launch"]         # SQ_ACTIVE_INST_VALU x 4, summed over the chip's SIMDs
                         peak = SIMDS * CLOCK_GHZ
                         fr["valu"] = {"achieved": busy / dur / 1e9, "peak": peak, "unit": "G SIMD-cycles/s", "per_launch": busy,
