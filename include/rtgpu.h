@@ -138,9 +138,10 @@ typedef struct rt_light {
     double   max_distance;        /* POINT / AREA */
     /* AREA only */
     uint32_t area_surface;        /* RT_AREA_* */
-    uint32_t area_iterations;
-    double   area_radius;
-    double   area_corners[4][3];
+    uint32_t area_iterations;     /* sample points per hit (area.rs:74-75, :117) */
+    double   area_radius;         /* RT_AREA_SPHERE */
+    double   area_corners[4][3];  /* RT_AREA_RECTANGLE: AreaSurface::Rectangle's array as it stands (area.rs:19), the
+                                     order blerp takes its corners in (area.rs:41-48, math/mod.rs:22-26) */
 } rt_light;
 
 /* skybox.rs:15,25,35-44.  CUBEMAP: 4x3 atlas, cell = w/4 = h/3 (:49-51). */
