@@ -312,8 +312,9 @@ int rt_detile_frames(rt_ctx* ctx, const void* d_gathered, uint32_t n_shards, uin
 int rt_cast_rays(rt_ctx* ctx, uint32_t n, const double* origins, const double* dirs,
                  rt_ray_hit* hits_out);
 
-/* rt_cast_rays for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments and results as
+/* rt_cast_rays for callers that must not allocate device memory: tight serving loops, harnesses that forbid
+ * hipMalloc.  It has no counterpart in the reference.  (The call copies from and to pageable host memory and waits for
+ * the context's stream, so it cannot itself be recorded into a HIP graph.)  Same arguments and results as
  * rt_cast_rays, but the rays and hit records are staged in a fixed array that lives in the library's device image
  * (RT_CAST_NOALLOC_MAX * 152 bytes, about 10 MB, held on every GPU the library runs on until the process ends), so
  * the call makes no hipMalloc / hipFree.  n above RT_CAST_NOALLOC_MAX is refused with RT_ERR_INVALID.  All contexts

@@ -32,6 +32,8 @@ hipError_t bvh_build_device(hipStream_t stream, const double* d_verts, const uin
 
 // Recomputes every triangle record and every box of an existing tree from new vertex positions (same connectivity).
 // d_tris' `orig` fields say which triangle each leaf-order position holds; nodes' pad words hold the parent links
-// (pad[0] parent record or RT_NONE, pad[1] slot in the parent, pad[2] number of inner children).  Synchronises the stream.
-hipError_t bvh_refit_device(hipStream_t stream, const double* d_verts, const uint32_t* d_tri_pos, uint32_t n_tris, DNode* nodes, uint32_t n_inner,
+// (pad[0] parent record or RT_NONE, pad[1] slot in the parent, pad[2] number of inner children).  n_records: how many
+// triangle records d_tris holds -- one per leaf entry, which is the triangle count only for a tree that lists every
+// triangle exactly once (a caller's tree may list one twice, or leave one out).  Synchronises the stream.
+hipError_t bvh_refit_device(hipStream_t stream, const double* d_verts, const uint32_t* d_tri_pos, uint32_t n_records, DNode* nodes, uint32_t n_inner,
                             uint32_t root_ref, DTri* tris, double root_box_out[6]);

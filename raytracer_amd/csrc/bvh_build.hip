@@ -82,7 +82,12 @@ __global__ __launch_bounds__(BB) void k_morton(const double* verts, const uint32
     }
     // quantised coordinates, bits[a] bits each
     u64 q[3];
-    for (int k = 0; k < 3; k++) q[k] = bits[k] > 0 ? (u64)(f[k] * (double)((1ull << bits[k]) - 1ull)) : 0ull;
+    // (beyond 53 bits the constant rounds up to 2^bits as a double and f = 1 would land one past the last cell: clamped)
+    for (int k = 0; k < 3; k++) {
+        const u64 top = bits[k] > 0 ? (1ull << bits[k]) - 1ull : 0ull;
+        const u64 v = bits[k] > 0 ? (u64)(f[k] * (double)top) : 0ull;
+        q[k] = v > top ? top : v;
+    }
     // the bits in that same order, most significant first
     u64 key = 0;
     int left[3] = {bits[0], bits[1], bits[2]};
@@ -281,7 +286,7 @@ size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
 
-hipError_t bvh_refit_device(hipStream_t s, const double* d_verts, const uint32_t* d_tri_pos, uint32_t n_tris, DNode* nodes, uint32_t n_inner,
+hipError_t bvh_refit_device(hipStream_t s, const double* d_verts, const uint32_t* d_tri_pos, uint32_t n_records, DNode* nodes, uint32_t n_inner,
                             uint32_t root_ref, DTri* tris, double root_box_out[6]) {
     hipError_t err = hipSuccess;
     char* tmp = nullptr;
@@ -291,7 +296,7 @@ hipError_t bvh_refit_device(hipStream_t s, const double* d_verts, const uint32_t
         uint32_t* arrive = reinterpret_cast<uint32_t*>(tmp);
         double* own = reinterpret_cast<double*>(tmp + b_arrive);
         double* root = reinterpret_cast<double*>(tmp + b_arrive + b_own);
-        hipLaunchKernelGGL(k_emit_tris, GRID(n_tris), dim3(BB), 0, s, d_verts, d_tri_pos, (const uint32_t*)nullptr, n_tris, tris, 0);
+        hipLaunchKernelGGL(k_emit_tris, GRID(n_records), dim3(BB), 0, s, d_verts, d_tri_pos, (const uint32_t*)nullptr, n_records, tris, 0);
         if (n_inner) {
             TRY(hipMemsetAsync(arrive, 0, b_arrive, s));
             hipLaunchKernelGGL(k_refit, GRID(n_inner), dim3(BB), 0, s, d_verts, d_tri_pos, nodes, n_inner, tris, arrive, own, root);

@@ -89,6 +89,7 @@ struct rt_ctx {
     struct MeshCopy {
         DMesh dm; std::vector<void*> allocs; size_t bytes = 0; uint32_t n_verts = 0, n_tris = 0, n_nodes = 0, n_prims = 0;
         uint32_t n_normals = 0;
+        uint32_t n_records = 0;                // triangle records on the device: one per leaf entry of a caller's tree (n_prims), one per triangle of a device-built one
         const uint32_t* d_tri_pos = nullptr;   // the triangles' vertex indices, kept for refits (rt_mesh::unchanged == 2)
     };
     std::vector<MeshCopy> mesh_copies;
@@ -137,6 +138,7 @@ struct rt_ctx {
     // level sizes of the last frame rendered for (shard, n_shards, vw, vh, max_depth): what the next such frame is given room for
     typedef std::tuple<uint32_t, uint32_t, int32_t, int32_t, uint32_t, uint32_t> LearnedKey;
     std::map<LearnedKey, std::vector<uint64_t>> learned;
+    uint64_t scene_shape = 0;                         // counts of the last uploaded scene (objects, lights, meshes, triangles): see scene_upload
     bool sync_levels = false;                         // RTGPU_SYNC_LEVELS=1: always read each level's size back before the next
     uint64_t respeculated = 0;                        // frames rendered twice because a level outgrew its room
     size_t scene_bytes = 0, work_bytes = 0;
@@ -310,6 +312,7 @@ int build_mesh_on_device(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc) {
         return fail(c, RT_ERR_UNSUPPORTED, "device-built BVH needs " + std::to_string(br.stack_need) + " stack entries (limit " + std::to_string(RT_PSTACK) +
                                                "): build this mesh's tree on the host");
     out.nodes = br.nodes; out.tris = br.tris; out.n_inner = br.n_inner; out.root_ref = br.root_ref;
+    mc.n_records = m.n_tris;
     set_root_box(out, br.root_box, br.root_box + 3);
     return upload_mesh_attributes(c, m, mc);
 }
@@ -319,6 +322,7 @@ int build_mesh_on_device(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc) {
 int refit_mesh(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc) {
     if (!m.verts) return fail(c, RT_ERR_INVALID, "mesh to refit without vertices");
     if (m.n_normals != mc.n_normals || (m.n_normals && !m.normals)) return fail(c, RT_ERR_INVALID, "mesh to refit: normals differ in number from the kept copy's");
+    if (mc.n_records == 0) return fail(c, RT_ERR_INVALID, "mesh to refit: the kept copy holds no triangle records");
     double* d_verts = nullptr;
     if (hipMalloc((void**)&d_verts, (size_t)m.n_verts * 24) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipMalloc failed during scene upload");
     hipError_t e = hipMemcpyAsync(d_verts, m.verts, (size_t)m.n_verts * 24, hipMemcpyHostToDevice, c->stream);
@@ -326,7 +330,7 @@ int refit_mesh(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc) {
         e = hipMemcpyAsync(const_cast<double*>(mc.dm.normals), m.normals, (size_t)m.n_normals * 24, hipMemcpyHostToDevice, c->stream);
     double root_box[6];
     if (e == hipSuccess)
-        e = bvh_refit_device(c->stream, d_verts, mc.d_tri_pos, mc.n_tris, const_cast<DNode*>(mc.dm.nodes), mc.dm.n_inner, mc.dm.root_ref,
+        e = bvh_refit_device(c->stream, d_verts, mc.d_tri_pos, mc.n_records, const_cast<DNode*>(mc.dm.nodes), mc.dm.n_inner, mc.dm.root_ref,
                              const_cast<DTri*>(mc.dm.tris), root_box);
     (void)hipFree(d_verts);
     if (e != hipSuccess) return fail(c, RT_ERR_DEVICE, std::string("device BVH refit: ") + hipGetErrorString(e));
@@ -566,6 +570,7 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc, bool rebalanc
     int rc;
     if ((rc = upload(c, nodes.data(), nodes.size(), &out.nodes)) != RT_OK) return rc;
     if ((rc = upload(c, tris.get(), (size_t)m.n_prims, &out.tris)) != RT_OK) return rc;
+    mc.n_records = m.n_prims;
     if ((rc = upload_mesh_attributes(c, m, mc)) != RT_OK) return rc;
     lap("copies");
     return RT_OK;
@@ -1043,12 +1048,20 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = scratch_address(device_id, &c->scratch)) != hipSuccess) return bail("hipGetSymbolAddress", e);
     {
-        // entries of the packets' node queue in use: all of them, unless a test asks for fewer to make it overflow
-        // (a variable of the device, so the last context created on a device decides)
-        uint32_t v = RT_NCAP;
-        if (const char* b = std::getenv("RTGPU_NODE_QUEUE")) v = (uint32_t)std::strtoul(b, nullptr, 10);
-        v = v < 4u ? 4u : (v > (uint32_t)RT_NCAP ? (uint32_t)RT_NCAP : v);
-        if ((e = hipMemcpyToSymbol(HIP_SYMBOL(rt_node_cap), &v, sizeof(v))) != hipSuccess) return bail("hipMemcpyToSymbol", e);
+        // A test knob, and the only state of the library that is not a context's own: how many entries of the packets'
+        // node queue the walks use is a variable of the device image, shared by every context on that device.  It is
+        // written only when RTGPU_NODE_QUEUE is set (tests make the queue overflow with it) or to undo such a write;
+        // in a process that never sets the variable, creating a context changes nothing outside that context.
+        static std::mutex mu;
+        static bool lowered[RT_MAX_DEVICES] = {};
+        std::lock_guard<std::mutex> lock(mu);
+        const char* b = std::getenv("RTGPU_NODE_QUEUE");
+        if (b || (device_id < RT_MAX_DEVICES && lowered[device_id])) {
+            uint32_t v = b ? (uint32_t)std::strtoul(b, nullptr, 10) : (uint32_t)RT_NCAP;
+            v = v < 4u ? 4u : (v > (uint32_t)RT_NCAP ? (uint32_t)RT_NCAP : v);
+            if ((e = hipMemcpyToSymbol(HIP_SYMBOL(rt_node_cap), &v, sizeof(v))) != hipSuccess) return bail("hipMemcpyToSymbol", e);
+            if (device_id < RT_MAX_DEVICES) lowered[device_id] = v != (uint32_t)RT_NCAP;
+        }
     }
     // (all streams at the default priority: mixed priorities hung the frame on this ROCm)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
@@ -1367,6 +1380,17 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     c->any_mesh_refracts = any_refr;
     c->total_tris = 0;
     for (uint32_t i = 0; i < d->n_meshes; i++) c->total_tris += d->meshes[i].n_tris;
+    {
+        // The level sizes learned from earlier frames say how much room the next frame's levels get.  They carry over to
+        // the next frame of a sequence (same objects, meshes kept or refitted), not to another scene that happens to
+        // have the same frame size: its first frame would be queued with the old scene's sizes and, outgrowing them,
+        // be rendered twice.
+        bool same = true;
+        for (uint32_t i = 0; i < d->n_meshes; i++) if (d->meshes[i].unchanged == 0) same = false;
+        const uint64_t shape = ((uint64_t)d->n_objects * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)H.n_lights << 40) ^ ((uint64_t)d->n_meshes << 20) ^ (c->total_tris << 1) ^ 1ull;
+        if (!same || shape != c->scene_shape) c->learned.clear();
+        c->scene_shape = shape;
+    }
     c->have_scene = true;
     c->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;

@@ -828,6 +828,59 @@ def test_refit_after_the_vertices_moved():
         assert_parity(got, got_ids, o_rgb, o_ids, exact_floor=0.9999)
 
 
+@pytest.mark.parametrize("prims,leaves", [
+    ([2, 0, 3, 1, 0], ((2, 0), (3, 1, 0))),     # triangle 0 listed in both leaves: five records for four triangles
+    ([2, 0, 3], ((2, 0), (3,))),                # triangle 1 in no leaf: three records (the reference would not see it either)
+], ids=["repeated-triangle", "omitted-triangle"])
+def test_refit_of_a_callers_tree_whose_leaf_list_is_not_a_permutation(prims, leaves):
+    """rt_mesh::unchanged == 2 on a caller-built tree (Mesh::sbvh is public, mesh.rs:118) whose leaf entries are not one
+    per triangle: the device holds one triangle record per leaf ENTRY, and the refit must recompute exactly those --
+    every one of them, and none beyond.  The refitted frame equals that of the same tree uploaded afresh with the moved
+    vertices, and the oracle's."""
+    verts = np.array([(-2, 0, -5), (0, 0, -5), (-1, 2, -5), (0.2, 0, -6), (2.2, 0, -6), (1.2, 2, -6),
+                      (-2, -2.5, -7), (0, -2.5, -7), (-1, -0.5, -7), (0.2, -2.5, -8), (2.2, -2.5, -8), (1.2, -0.5, -8)], dtype=float)
+    tris = [(0, 1, 2), (3, 4, 5), (6, 7, 8), (9, 10, 11)]
+    moved = verts.copy()
+    moved[:, 0] += 0.35 * np.sin(verts[:, 1] + 0.5)
+    moved[:, 1] += 0.3 * np.cos(verts[:, 0] * 1.3)
+    moved[:, 2] -= 0.2 * (np.arange(len(verts)) % 3)
+
+    def scene_of(v):
+        m = ra.Mesh(scenes.sdl_material(ra.Texture.solid((200, 120, 60)), reflectiveness=0.2))
+        m.set_geometry(v, tris).recalculate_normals()
+        def box(ts):
+            p = np.asarray(v)[np.array([tris[t] for t in ts]).ravel()]
+            return p.min(0), p.max(0)
+        nodes = np.zeros(3, dtype=ra.Mesh.BVH_NODE)
+        nodes[0] = (*box(sorted(set(leaves[0] + leaves[1]))), 2, 0)
+        nodes[1] = (*box(leaves[0]), 0, len(leaves[0]))
+        nodes[2] = (*box(leaves[1]), len(leaves[0]), len(leaves[1]))
+        m.set_bvh(nodes, prims, depth=2)
+        s = ra.Scene()
+        s.set_camera(ra.Camera(vw=96, vh=72, origin=(0.1, 0.2, 2.0)))
+        s.add_light(scenes.sdl_sun((-0.3, -1, -0.6)))
+        s.add(ra.Plane((0, -3, 0), (0, 1, 0), scenes.sdl_material(ra.Texture.checkerboard((220, 220, 220), (40, 40, 40)))))
+        s.add(m)
+        return s
+
+    s = scene_of(verts)
+    with ra.Context(0) as ctx:
+        ctx.upload(s)
+        before = ctx.render()[0]
+        s.mesh_at(1).set_verts(moved).recalculate_normals()
+        ctx.upload(s, keep_meshes="refit")
+        got, got_ids, st = ctx.render(ids=True)
+        fresh = scene_of(moved)
+        ctx.upload(fresh)
+        want, want_ids, st2 = ctx.render(ids=True)
+    assert not np.array_equal(before, got)
+    assert np.array_equal(got, want) and np.array_equal(got_ids, want_ids) and ray_counts(st) == ray_counts(st2)
+    o_rgb, o_ids, _, _ = oracle.render(fresh, 0)
+    assert_parity(got, got_ids, o_rgb, o_ids, exact_floor=0.9999)
+    seen = set(np.unique(got_ids[..., 1][got_ids[..., 0] == 1]).tolist())
+    assert seen == set(prims), seen          # every listed triangle is in view, an omitted one is not hit
+
+
 def test_shared_reciprocal_divisions_equal_the_plain_ones():
     """dev_rt.h div_by_norm (a vector over its own magnitude: three f64 divisions through one refined reciprocal) against
     the compiler's own divisions, bit for bit: 3.7e9 random vectors whose components' exponents sweep +-2 ... +-1000, with
