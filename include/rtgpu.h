@@ -229,6 +229,20 @@ typedef struct rt_ctx rt_ctx;
 int rt_ctx_create(int device_id, rt_ctx** out);
 void rt_ctx_destroy(rt_ctx* ctx);
 
+/* One context over n_devices GPUs of this node, for the reference's callers as they are: one process that asks for
+ * one frame at a time (sdl/src/main.rs:61, :91 -> scene.rs:249-250 -> Scene::render, scene.rs:220).  The context is
+ * used like any other -- rt_scene_upload puts the scene on every device, rt_render and rt_render_frames return whole
+ * frames in host memory, rt_set_area_seed and rt_ctx_destroy reach every device -- and inside it device k renders
+ * image-space shard k of n_devices (pixels are independent, scene.rs:239-242), the compact shard buffers are gathered
+ * to device_ids[0] with RCCL (ncclGather, one communicator per device inside this process; librccl is opened when
+ * the first such context is created) and device_ids[0] assembles the frame.  n_devices == 1 is rt_ctx_create: no
+ * collective, no RCCL.  The entry points that take device pointers (rt_render_shard, rt_render_shard_batch,
+ * rt_detile, rt_detile_frames) and the probes (rt_cast_rays, rt_cast_rays_noalloc) address device_ids[0] alone.
+ * A list that names one GPU more than once (several shards on one GPU: a rehearsal on a small machine) is gathered
+ * with device-to-device copies, RCCL having no such communicator. */
+int rt_ctx_create_multi(const int* device_ids, int n_devices, rt_ctx** out);
+int rt_ctx_device_count(const rt_ctx* ctx);   /* 1 for a context of rt_ctx_create, 0 for NULL */
+
 /* Text of the last failure on this context (or of the last failed
  * rt_ctx_create when ctx is NULL).  Never NULL. */
 const char* rt_last_error(const rt_ctx* ctx);
@@ -305,6 +319,29 @@ int rt_render_shard_batch(rt_ctx* ctx, uint32_t shard, uint32_t n_shards, uint32
  * d_images receives n_frames row-major images one after the other. */
 int rt_detile_frames(rt_ctx* ctx, const void* d_gathered, uint32_t n_shards, uint32_t n_frames,
                      int64_t slots_per_shard, uint32_t elem_bytes, void* d_images);
+
+/* The sequence workload behind the reference's own entry point (sdl/src/main.rs:84-92: frame after frame, each
+ * through Scene::render, scene.rs:220): n_frames frames of a camera path through the uploaded scene, rendered as one
+ * set of launches on every device of the context and returned as whole frames in HOST memory, one after the other
+ * (rgb_out: n_frames * vw*vh*3 bytes; prim_id_out: nullable, n_frames * vw*vh * 2 u32).  cameras[f].vw/vh must equal
+ * the uploaded scene's; cameras == NULL holds the scene's own view.  1 <= n_frames <= RT_BATCH_MAX.  On a context
+ * over several GPUs each device renders its shard of every frame and one gather moves the whole set. */
+int rt_render_frames(rt_ctx* ctx, uint32_t n_frames, const rt_camera* cameras, uint8_t* rgb_out, uint32_t* prim_id_out,
+                     rt_stats* stats_out);
+
+/* How a context over n_devices GPUs lays out a set of n_frames frames (no GPU needed; the library uses these figures
+ * itself): every device contributes the same count to the gather, its shard padded to the largest one (shard 0's).
+ *   slots_per_shard     rt_shard_pixels(vw, vh, 0, n_devices)
+ *   part_bytes_*        one device's compact buffer: [frame][slot]
+ *   gathered_bytes_*    on the first device: [shard][frame][slot], device k's part at k * part_bytes
+ *   frame_bytes_rgb     one assembled frame */
+typedef struct rt_multi_plan {
+    int64_t slots_per_shard;
+    int64_t part_bytes_rgb, part_bytes_ids;
+    int64_t gathered_bytes_rgb, gathered_bytes_ids;
+    int64_t frame_bytes_rgb;
+} rt_multi_plan;
+int rt_multi_layout(int32_t vw, int32_t vh, uint32_t n_devices, uint32_t n_frames, rt_multi_plan* out);
 
 /* Probe: casts n arbitrary rays through the uploaded scene with the semantics
  * of Scene::cast_ray_once (scene.rs:79-82); host pointers.

@@ -54,6 +54,12 @@ class RtCamera(C.Structure):
                 ("yaw", C.c_double), ("pitch", C.c_double), ("fov", C.c_double), ("chf", C.c_double)]
 
 
+class RtMultiPlan(C.Structure):
+    """rt_multi_plan of include/rtgpu.h: how a context over several GPUs lays out a set of frames"""
+    _fields_ = [("slots_per_shard", C.c_int64), ("part_bytes_rgb", C.c_int64), ("part_bytes_ids", C.c_int64),
+                ("gathered_bytes_rgb", C.c_int64), ("gathered_bytes_ids", C.c_int64), ("frame_bytes_rgb", C.c_int64)]
+
+
 class RtRayHit(C.Structure):
     _fields_ = [
         ("object", C.c_uint32), ("prim", C.c_uint32),
@@ -87,6 +93,7 @@ GPU_SYMBOLS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload", "rt_render",
     "rt_shard_pixels", "rt_supertile", "rt_render_shard", "rt_detile", "rt_cast_rays", "rt_cast_rays_noalloc",
     "rt_render_shard_batch", "rt_detile_frames", "rt_set_area_seed",
+    "rt_ctx_create_multi", "rt_ctx_device_count", "rt_render_frames", "rt_multi_layout",
 ]
 
 
@@ -122,6 +129,14 @@ def gpu():
         L.rt_cast_rays_noalloc.restype = C.c_int
         L.rt_set_area_seed.argtypes = [C.c_void_p, C.c_uint64]
         L.rt_set_area_seed.restype = C.c_int
+        L.rt_ctx_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_ctx_create_multi.restype = C.c_int
+        L.rt_ctx_device_count.argtypes = [C.c_void_p]
+        L.rt_ctx_device_count.restype = C.c_int
+        L.rt_render_frames.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RtStats)]
+        L.rt_render_frames.restype = C.c_int
+        L.rt_multi_layout.argtypes = [C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(RtMultiPlan)]
+        L.rt_multi_layout.restype = C.c_int
         _gpu = L
     return _gpu
 

@@ -5,6 +5,8 @@
 // depths, and the copy-out.  There is no CPU rendering path in this library: a
 // missing device is an error.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is opened when the first context over several GPUs is created
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -143,6 +145,8 @@ struct rt_ctx {
     uint64_t respeculated = 0;                        // frames rendered twice because a level outgrew its room
     size_t scene_bytes = 0, work_bytes = 0;
     double ms_upload = 0.;
+    struct rt_multi* multi = nullptr;                 // a context over several GPUs (rt_ctx_create_multi): this one is its first member
+    struct rt_multi* solo = nullptr;                  // a one-device context's buffers for sets of frames (rt_render_frames), made on first use
 };
 
 namespace {
@@ -1079,8 +1083,10 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     return RT_OK;
 }
 
+static void multi_destroy(rt_ctx* head);
 void rt_ctx_destroy(rt_ctx* c) {
     if (!c) return;
+    if (c->multi || c->solo) multi_destroy(c);   // the other members, the communicators and the gather buffers; then this context like any other
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto ss : c->side) if (ss) (void)hipStreamSynchronize(ss);
@@ -1115,8 +1121,13 @@ void rt_ctx_destroy(rt_ctx* c) {
 const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 static int scene_upload(rt_ctx* c, const rt_scene_desc* d);
+static int upload_one(rt_ctx* c, const rt_scene_desc* d);
+static int multi_upload(rt_ctx* head, const rt_scene_desc* d);
 int rt_scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     if (!c) return RT_ERR_INVALID;
+    return c->multi ? multi_upload(c, d) : upload_one(c, d);
+}
+static int upload_one(rt_ctx* c, const rt_scene_desc* d) {
     const int rc = scene_upload(c, d);
     if (rc != RT_OK) {   // a failed upload leaves nothing behind, kept meshes included
         (void)hipSetDevice(c->device);
@@ -1444,8 +1455,13 @@ static int copy_frame_to_host(rt_ctx* c, void* dst, const void* d_src, size_t by
     return RT_OK;
 }
 
+static int seed_one(rt_ctx* c, uint64_t seed);
+static int multi_seed(rt_ctx* head, uint64_t seed);
 int rt_set_area_seed(rt_ctx* c, uint64_t seed) {
     if (!c) return RT_ERR_INVALID;
+    return c->multi ? multi_seed(c, seed) : seed_one(c, seed);
+}
+static int seed_one(rt_ctx* c, uint64_t seed) {
     c->area_seed = seed;
     if (c->have_scene) {
         HIP_TRY(c, hipSetDevice(c->device));
@@ -1455,10 +1471,12 @@ int rt_set_area_seed(rt_ctx* c, uint64_t seed) {
     return RT_OK;
 }
 
+static int multi_render(rt_ctx* head, struct rt_multi& M, uint32_t n_frames, const rt_camera* cameras, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* stats_out);
 int rt_render(rt_ctx* c, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* stats_out) {
     if (!c) return RT_ERR_INVALID;
     if (!rgb_out) return fail(c, RT_ERR_INVALID, "rgb_out is NULL");
     if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
+    if (c->multi) return multi_render(c, *c->multi, 1, nullptr, rgb_out, prim_id_out, stats_out);
     auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t px = (size_t)c->vw * (size_t)c->vh;
@@ -1607,6 +1625,323 @@ int rt_cast_rays_noalloc(rt_ctx* c, uint32_t n, const double* origins, const dou
     HIP_TRY(c, hipMemcpyAsync(hits_out, d_h, (size_t)n * sizeof(DProbeHit), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
+}
+
+// ---- One context over several GPUs of a node (rt_ctx_create_multi) ---------------------------------------------------
+//
+// The reference's callers are one process that asks for one frame (sdl/src/main.rs:61,91 -> scene.rs:249-250 ->
+// scene.rs:220).  For that caller several GPUs must look like one context: the scene goes to every device at upload,
+// device k renders shard k of n (the image-space shards of rt_render_shard, pixels being independent, scene.rs:239-242),
+// the compact shard buffers are gathered to the first device -- RCCL's ncclGather over the devices' direct links, one
+// communicator per device inside this process -- and the first device puts the frame together (k_detile) and copies
+// it out.  One host thread per device drives its shard; there is no exchange between devices other than that gather.
+//
+// RCCL is opened with dlopen when the first such context is created: a process that renders on one GPU never loads it.
+// A device list that names a GPU twice (two shards on one GPU: a rehearsal of the n > 1 path on a one-GPU machine, which
+// RCCL refuses) is gathered with device-to-device copies instead; RTGPU_MULTI_GATHER=copy asks for that outright.
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static std::mutex g_rccl_mutex;
+static RcclApi g_rccl;
+static const RcclApi* rccl_api(std::string& err) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.handle) return &g_rccl;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) { const char* e = dlerror(); err = std::string("librccl could not be opened: ") + (e ? e : "?"); return nullptr; }
+    RcclApi a;
+    a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    a.Gather = reinterpret_cast<decltype(a.Gather)>(dlsym(h, "ncclGather"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!a.CommInitAll || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Gather || !a.GetErrorString) {
+        err = "librccl lacks one of ncclCommInitAll / ncclCommDestroy / ncclGroupStart / ncclGroupEnd / ncclGather / ncclGetErrorString";
+        dlclose(h);
+        return nullptr;
+    }
+    a.handle = h;
+    g_rccl = a;
+    return &g_rccl;
+}
+
+struct rt_multi {
+    std::vector<rt_ctx*> member;      // member[0] is the context the caller holds; member[k] renders shard k
+    std::vector<int> device;
+    const RcclApi* api = nullptr;     // NULL: gathered with device-to-device copies
+    std::vector<ncclComm_t> comm;
+    // a member's compact shard buffers, on its device (the first member's are the head of the gathered buffers)
+    struct Part { void* rgb = nullptr; size_t rgb_cap = 0; void* ids = nullptr; size_t ids_cap = 0; int rc = RT_OK; rt_stats st; };
+    std::vector<Part> part;
+    void* gath_rgb = nullptr; size_t gath_rgb_cap = 0;     // on the first device: [shard][frame][slot]
+    void* gath_ids = nullptr; size_t gath_ids_cap = 0;
+    void* frames = nullptr; size_t frames_cap = 0;         // on the first device: the row-major frames of a set
+};
+
+int rt_multi_layout(int32_t vw, int32_t vh, uint32_t n_devices, uint32_t n_frames, rt_multi_plan* out) {
+    if (!out || vw <= 0 || vh <= 0 || n_devices == 0 || n_frames == 0 || n_frames > RT_BATCH_MAX) return RT_ERR_INVALID;
+    // every device contributes the same count to the gather: its shard padded to the largest one, shard 0's
+    const int64_t slots = rt_shard_pixels(vw, vh, 0, n_devices);
+    if (slots <= 0 || (uint64_t)slots * n_frames >= 0x7FFFFFFFull) return RT_ERR_UNSUPPORTED;
+    out->slots_per_shard = slots;
+    out->part_bytes_rgb = slots * 3 * (int64_t)n_frames;
+    out->part_bytes_ids = slots * 8 * (int64_t)n_frames;
+    out->gathered_bytes_rgb = out->part_bytes_rgb * (int64_t)n_devices;
+    out->gathered_bytes_ids = out->part_bytes_ids * (int64_t)n_devices;
+    out->frame_bytes_rgb = (int64_t)vw * vh * 3;
+    return RT_OK;
+}
+
+int rt_ctx_device_count(const rt_ctx* c) { return !c ? 0 : c->multi ? (int)c->multi->member.size() : 1; }
+
+int rt_ctx_create_multi(const int* device_ids, int n_devices, rt_ctx** out) {
+    if (!out) { g_create_error = "rt_ctx_create_multi: out is NULL"; return RT_ERR_INVALID; }
+    *out = nullptr;
+    if (!device_ids || n_devices <= 0 || n_devices > RT_MAX_DEVICES) { g_create_error = "rt_ctx_create_multi: bad device list"; return RT_ERR_INVALID; }
+    // one device: the context of rt_ctx_create, and no collective anywhere (RTGPU_MULTI_FORCE=1 keeps the gather
+    // machinery even then, so that a one-GPU machine can run the RCCL calls: a communicator of one rank)
+    const char* force = std::getenv("RTGPU_MULTI_FORCE");
+    if (n_devices == 1 && !(force && force[0] == '1')) return rt_ctx_create(device_ids[0], out);
+    std::unique_ptr<rt_multi> M(new (std::nothrow) rt_multi());
+    if (!M) { g_create_error = "out of host memory"; return RT_ERR_NOMEM; }
+    auto undo = [&]() { for (rt_ctx* m : M->member) rt_ctx_destroy(m); M->member.clear(); };
+    for (int k = 0; k < n_devices; k++) {
+        rt_ctx* m = nullptr;
+        const int rc = rt_ctx_create(device_ids[k], &m);
+        if (rc != RT_OK) { g_create_error = "device " + std::to_string(device_ids[k]) + ": " + g_create_error; undo(); return rc; }
+        M->member.push_back(m);
+        M->device.push_back(device_ids[k]);
+    }
+    M->part.resize((size_t)n_devices);
+    bool repeated = false;
+    for (int a = 0; a < n_devices; a++) for (int b = a + 1; b < n_devices; b++) if (device_ids[a] == device_ids[b]) repeated = true;
+    const char* how = std::getenv("RTGPU_MULTI_GATHER");
+    const bool by_copy = repeated || (how && std::string(how) == "copy");
+    if (!by_copy) {
+        std::string err;
+        M->api = rccl_api(err);
+        if (!M->api) { g_create_error = err; undo(); return RT_ERR_DEVICE; }
+        M->comm.assign((size_t)n_devices, nullptr);
+        const ncclResult_t r = M->api->CommInitAll(M->comm.data(), n_devices, device_ids);
+        if (r != ncclSuccess) {
+            g_create_error = std::string("ncclCommInitAll: ") + M->api->GetErrorString(r);
+            M->comm.clear(); undo();
+            return RT_ERR_DEVICE;
+        }
+    }
+    rt_ctx* head = M->member[0];
+    head->multi = M.release();
+    (void)hipSetDevice(head->device);
+    *out = head;
+    return RT_OK;
+}
+
+static void multi_destroy(rt_ctx* head) {
+    if (head->solo) {
+        rt_multi* S = head->solo;
+        head->solo = nullptr;
+        (void)hipSetDevice(head->device);
+        if (head->stream) (void)hipStreamSynchronize(head->stream);
+        if (S->gath_rgb) (void)hipFree(S->gath_rgb);
+        if (S->gath_ids) (void)hipFree(S->gath_ids);
+        if (S->frames) (void)hipFree(S->frames);
+        delete S;
+    }
+    rt_multi* M = head->multi;
+    if (!M) return;
+    head->multi = nullptr;
+    for (size_t k = 0; k < M->member.size(); k++) {
+        rt_ctx* m = M->member[k];
+        (void)hipSetDevice(m->device);
+        if (m->stream) (void)hipStreamSynchronize(m->stream);
+        if (k > 0) {
+            if (M->part[k].rgb) (void)hipFree(M->part[k].rgb);
+            if (M->part[k].ids) (void)hipFree(M->part[k].ids);
+        }
+    }
+    if (M->api) for (ncclComm_t cm : M->comm) if (cm) (void)M->api->CommDestroy(cm);
+    (void)hipSetDevice(head->device);
+    if (M->gath_rgb) (void)hipFree(M->gath_rgb);
+    if (M->gath_ids) (void)hipFree(M->gath_ids);
+    if (M->frames) (void)hipFree(M->frames);
+    for (size_t k = 1; k < M->member.size(); k++) rt_ctx_destroy(M->member[k]);
+    delete M;
+}
+
+// fn(k) for every member, each on a host thread of its own (the first on the calling thread); the first failure's code,
+// its message filed in the head context with the device it came from
+extern "C++" {
+template <typename F>
+static int multi_each(rt_ctx* head, rt_multi& M, F fn) {
+    const size_t n = M.member.size();
+    std::vector<int> rc(n, RT_OK);
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < n; k++) th.emplace_back([&, k]() { rc[k] = fn(k); });
+    rc[0] = fn(0);
+    for (auto& t : th) t.join();
+    (void)hipSetDevice(head->device);
+    for (size_t k = 0; k < n; k++)
+        if (rc[k] != RT_OK) {
+            if (k > 0) head->err = "device " + std::to_string(M.device[k]) + " (shard " + std::to_string(k) + "): " + M.member[k]->err;
+            return rc[k];
+        }
+    return RT_OK;
+}
+}  // extern "C++"
+
+static int multi_upload(rt_ctx* head, const rt_scene_desc* d) {
+    rt_multi& M = *head->multi;
+    // every device gets its own deep copy of the scene (a few hundred megabytes at most against 288 GB per device),
+    // re-emitted by that member's own host thread; rt_mesh::unchanged means the same on every member
+    const int rc = multi_each(head, M, [&](size_t k) { return upload_one(M.member[k], d); });
+    if (rc != RT_OK) {   // a failed upload leaves nothing behind on any device
+        const std::string keep = head->err;
+        for (rt_ctx* m : M.member) { (void)hipSetDevice(m->device); free_scene(m); free_mesh_copies(m->mesh_copies); }
+        (void)hipSetDevice(head->device);
+        head->err = keep;
+    }
+    return rc;
+}
+
+static int multi_seed(rt_ctx* head, uint64_t seed) {
+    rt_multi& M = *head->multi;
+    for (size_t k = 0; k < M.member.size(); k++) {
+        const int rc = seed_one(M.member[k], seed);
+        if (rc != RT_OK) { if (k > 0) head->err = M.member[k]->err; (void)hipSetDevice(head->device); return rc; }
+    }
+    (void)hipSetDevice(head->device);
+    return RT_OK;
+}
+
+// the members' compact buffers -> the first device, shard-major
+static int multi_gather(rt_ctx* head, rt_multi& M, bool ids, size_t bytes_per_member) {
+    const size_t n = M.member.size();
+    char* gath = static_cast<char*>(ids ? M.gath_ids : M.gath_rgb);
+    auto src = [&](size_t k) { return static_cast<const char*>(k == 0 ? (const void*)gath : (ids ? M.part[k].ids : M.part[k].rgb)); };
+    if (M.api) {
+        // one ncclGather per device, issued from this one thread as a group; the first member's own part already lies
+        // where the gather would put it (in place: sendbuff == recvbuff + rank * count)
+        ncclResult_t r = M.api->GroupStart();
+        for (size_t k = 0; k < n && r == ncclSuccess; k++) {
+            (void)hipSetDevice(M.device[k]);
+            r = M.api->Gather(src(k), k == 0 ? gath : nullptr, bytes_per_member, ncclUint8, 0, M.comm[k], M.member[k]->stream);
+        }
+        const ncclResult_t r2 = M.api->GroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) { (void)hipSetDevice(head->device); return fail(head, RT_ERR_DEVICE, std::string("ncclGather: ") + M.api->GetErrorString(r)); }
+        // the senders' buffers are free again, and the gathered bytes in place, once every stream has run its part
+        for (size_t k = n; k-- > 0;) {
+            (void)hipSetDevice(M.device[k]);
+            const hipError_t e = hipStreamSynchronize(M.member[k]->stream);
+            if (e != hipSuccess) { (void)hipSetDevice(head->device); return fail(head, RT_ERR_DEVICE, std::string("gather: ") + hipGetErrorString(e)); }
+        }
+    } else {
+        (void)hipSetDevice(head->device);
+        for (size_t k = 1; k < n; k++)
+            HIP_TRY(head, hipMemcpyPeerAsync(gath + k * bytes_per_member, head->device, src(k), M.device[k], bytes_per_member, head->stream));
+        HIP_TRY(head, hipStreamSynchronize(head->stream));
+    }
+    (void)hipSetDevice(head->device);
+    return RT_OK;
+}
+
+// n_frames frames (cameras == NULL: the uploaded scene's own view) over all members: render, gather, put together, copy out
+static int multi_render(rt_ctx* head, rt_multi& M, uint32_t n_frames, const rt_camera* cameras, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* stats_out) {
+    const uint32_t n = (uint32_t)M.member.size();
+    auto t0 = std::chrono::steady_clock::now();
+    rt_multi_plan plan;
+    {
+        const int prc = rt_multi_layout(head->vw, head->vh, n, n_frames, &plan);
+        if (prc != RT_OK) return fail(head, prc, "frame (or set of frames) too large for one set of launches");
+    }
+    HIP_TRY(head, hipSetDevice(head->device));
+    int rc;
+    if ((rc = ensure_buf(head, &M.gath_rgb, &M.gath_rgb_cap, (size_t)plan.gathered_bytes_rgb)) != RT_OK) return rc;
+    if (prim_id_out && (rc = ensure_buf(head, &M.gath_ids, &M.gath_ids_cap, (size_t)plan.gathered_bytes_ids)) != RT_OK) return rc;
+    if ((rc = ensure_buf(head, &M.frames, &M.frames_cap, (size_t)plan.frame_bytes_rgb * n_frames)) != RT_OK) return rc;
+    if (prim_id_out && (rc = ensure_buf(head, &head->d_ids2, &head->d_ids2_cap, (size_t)head->vw * head->vh * 8 * n_frames)) != RT_OK) return rc;
+    rc = multi_each(head, M, [&](size_t k) -> int {
+        rt_ctx* m = M.member[k];
+        rt_multi::Part& P = M.part[k];
+        if (hipSetDevice(m->device) != hipSuccess) return fail(m, RT_ERR_DEVICE, "hipSetDevice failed");
+        void *rgb = M.gath_rgb, *ids = prim_id_out ? M.gath_ids : nullptr;
+        if (k > 0) {
+            int r;
+            if ((r = ensure_buf(m, &P.rgb, &P.rgb_cap, (size_t)plan.part_bytes_rgb)) != RT_OK) return r;
+            if (prim_id_out && (r = ensure_buf(m, &P.ids, &P.ids_cap, (size_t)plan.part_bytes_ids)) != RT_OK) return r;
+            rgb = P.rgb; ids = prim_id_out ? P.ids : nullptr;
+        }
+        if (n_frames == 1 && !cameras) return rt_render_shard(m, (uint32_t)k, n, rgb, ids, &P.st);
+        return rt_render_shard_batch(m, (uint32_t)k, n, n_frames, cameras, plan.slots_per_shard, rgb, ids, &P.st);
+    });
+    if (rc != RT_OK) return rc;
+    if (n > 1 || M.api) {
+        if ((rc = multi_gather(head, M, false, (size_t)plan.part_bytes_rgb)) != RT_OK) return rc;
+        if (prim_id_out && (rc = multi_gather(head, M, true, (size_t)plan.part_bytes_ids)) != RT_OK) return rc;
+    }
+    if ((rc = rt_detile_frames(head, M.gath_rgb, n, n_frames, plan.slots_per_shard, 3, M.frames)) != RT_OK) return rc;
+    if (prim_id_out) {
+        if ((rc = rt_detile_frames(head, M.gath_ids, n, n_frames, plan.slots_per_shard, 8, head->d_ids2)) != RT_OK) return rc;
+        HIP_TRY(head, hipMemcpyAsync(prim_id_out, head->d_ids2, (size_t)head->vw * head->vh * 8 * n_frames, hipMemcpyDeviceToHost, head->stream));
+    }
+    if ((rc = copy_frame_to_host(head, rgb_out, M.frames, (size_t)plan.frame_bytes_rgb * n_frames)) != RT_OK) return rc;
+    HIP_TRY(head, hipGetLastError());
+    if (stats_out) {
+        // rays add up over the shards; times are the slowest member's (the members work side by side)
+        rt_stats st = M.part[0].st;
+        for (uint32_t k = 1; k < n; k++) {
+            const rt_stats& p = M.part[k].st;
+            st.rays_primary += p.rays_primary; st.rays_reflect += p.rays_reflect; st.rays_transmit += p.rays_transmit; st.rays_shadow += p.rays_shadow;
+            for (int d = 0; d < 8; d++) st.rays_per_level[d] += p.rays_per_level[d];
+            st.ms_render = std::max(st.ms_render, p.ms_render); st.ms_trace = std::max(st.ms_trace, p.ms_trace);
+            st.ms_shadow = std::max(st.ms_shadow, p.ms_shadow); st.ms_shade = std::max(st.ms_shade, p.ms_shade);
+            st.ms_resolve = std::max(st.ms_resolve, p.ms_resolve); st.ms_upload = std::max(st.ms_upload, p.ms_upload);
+            st.ms_shadow_main = std::max(st.ms_shadow_main, p.ms_shadow_main);
+            st.device_bytes += p.device_bytes;
+            st.nodes_visited += p.nodes_visited; st.tris_tested += p.tris_tested; st.wave_nodes += p.wave_nodes; st.wave_tris += p.wave_tris;
+            st.long_trace += p.long_trace; st.long_shadow += p.long_shadow; st.bytes_fetched += p.bytes_fetched; st.bytes_fetched_main += p.bytes_fetched_main;
+            st.max_lane_steps = std::max(st.max_lane_steps, p.max_lane_steps); st.max_wave_steps = std::max(st.max_wave_steps, p.max_wave_steps);
+            st.speculative = st.speculative && p.speculative ? 1u : 0u;
+            st.respeculated += p.respeculated;
+        }
+        st.device_bytes += M.gath_rgb_cap + M.gath_ids_cap + M.frames_cap;
+        st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        *stats_out = st;
+    }
+    return RT_OK;
+}
+
+int rt_render_frames(rt_ctx* c, uint32_t n_frames, const rt_camera* cameras, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* stats_out) {
+    if (!c) return RT_ERR_INVALID;
+    if (!rgb_out) return fail(c, RT_ERR_INVALID, "rgb_out is NULL");
+    if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
+    if (n_frames == 0 || n_frames > RT_BATCH_MAX) return fail(c, RT_ERR_INVALID, "rt_render_frames: n_frames must be 1.." + std::to_string(RT_BATCH_MAX));
+    if (cameras)
+        for (uint32_t f = 0; f < n_frames; f++)
+            if (cameras[f].vw != c->vw || cameras[f].vh != c->vh)
+                return fail(c, RT_ERR_INVALID, "rt_render_frames: camera " + std::to_string(f) + " has another frame size than the uploaded scene");
+    if (!c->multi) {
+        // a context on one device renders its sets of frames the same way: one member, no gather.  Its buffers are kept
+        // beside the context for the next set (rt_ctx_destroy frees them); the other entry points do not look at them.
+        if (!c->solo) {
+            c->solo = new (std::nothrow) rt_multi();
+            if (!c->solo) return fail(c, RT_ERR_NOMEM, "out of host memory");
+            c->solo->member.push_back(c); c->solo->device.push_back(c->device); c->solo->part.resize(1);
+        }
+        return multi_render(c, *c->solo, n_frames, cameras, rgb_out, prim_id_out, stats_out);
+    }
+    return multi_render(c, *c->multi, n_frames, cameras, rgb_out, prim_id_out, stats_out);
 }
 
 }  // extern "C"

@@ -8,13 +8,25 @@ from . import _native as N
 
 
 class Context:
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, devices=None):
+        """device_id: one GPU (rt_ctx_create).  devices=[ids]: one context over several GPUs of this node
+        (rt_ctx_create_multi): upload() reaches every device, render() and render_frames() shard the frame over them,
+        gather the shards to the first device inside the library (RCCL) and return whole frames."""
         self._c = C.c_void_p()
-        rc = N.gpu().rt_ctx_create(int(device_id), C.byref(self._c))
+        if devices is None:
+            rc = N.gpu().rt_ctx_create(int(device_id), C.byref(self._c))
+        else:
+            ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+            rc = N.gpu().rt_ctx_create_multi(ids, len(devices), C.byref(self._c))
+            device_id = int(devices[0]) if len(devices) else 0
         if rc != N.RT_OK:
             raise N.RtError(rc, N.gpu().rt_last_error(None).decode(errors="replace"))
         self.device_id = device_id
         self.vw = self.vh = 0
+
+    @property
+    def n_devices(self):
+        return N.gpu().rt_ctx_device_count(self._c)
 
     def __enter__(self):
         return self
@@ -62,6 +74,21 @@ class Context:
         idb = np.empty((self.vh, self.vw, 2), dtype=np.uint32) if ids else None
         st = N.RtStats()
         self._check(N.gpu().rt_render(self._c, rgb.ctypes.data, idb.ctypes.data if ids else None, C.byref(st)))
+        return rgb, idb, st
+
+    def render_frames(self, cameras, ids=False):
+        """rt_render_frames: the frames of a camera path through the uploaded scene as one set of launches (on every
+        device of the context) -> (rgb (n, vh, vw, 3) u8, ids (n, vh, vw, 2) u32 or None, RtStats).  `cameras`: Camera
+        objects, a ready rt_camera array (camera_array), or a frame count (the scene's own view that many times)."""
+        if isinstance(cameras, int):
+            n, arr = cameras, None
+        else:
+            arr = cameras if isinstance(cameras, C.Array) else self.camera_array(cameras)
+            n = len(arr)
+        rgb = np.empty((n, self.vh, self.vw, 3), dtype=np.uint8)
+        idb = np.empty((n, self.vh, self.vw, 2), dtype=np.uint32) if ids else None
+        st = N.RtStats()
+        self._check(N.gpu().rt_render_frames(self._c, n, arr, rgb.ctypes.data, idb.ctypes.data if ids else None, C.byref(st)))
         return rgb, idb, st
 
     def shard_pixels(self, shard, n_shards):
