@@ -87,6 +87,8 @@ def lib():
         L.orc_powi.restype = C.c_double
         L.orc_set_area_seed.argtypes = [C.c_uint64]
         L.orc_set_area_seed.restype = None
+        L.orc_set_mistake.argtypes = [C.c_uint32]
+        L.orc_set_mistake.restype = None
         _lib = L
     return _lib
 
@@ -97,6 +99,13 @@ DEFAULT_AREA_SEED = 0x9E3779B97F4A7C15
 def set_area_seed(seed=DEFAULT_AREA_SEED):
     """Seed of the stand-in for area.rs:121's unseeded generator, for the renders that follow."""
     lib().orc_set_area_seed(seed)
+
+
+def set_mistake(flags=0):
+    """Negative controls: 1 = cubemap texels from the nearest texel instead of the four-tap blend, 2 = two entries of
+    the cubemap's face table exchanged; 0 = the reference's behaviour.  A test against a reference-held render must
+    fail with either switched on."""
+    lib().orc_set_mistake(flags)
 
 
 def render(scene, n_threads=0, pixels=None, ids=True):

@@ -23,11 +23,17 @@
  * as well, and no longer so with the sphere's index of refraction at 1.45;
  * likewise the two Cornell boxes of scenes/cornell_icosahedron.sdl
  * (11_22_2021_6.png, _7.png: a mesh under the area light) --
+ * and the sky of two more (images/readme/10_4_2021.png, 10_4_2021_2.png:
+ * 1,574,249 pixels seen through the cubemap of assets/storforsen_4.jpg) to
+ * the byte, which pins Cubemap::ray_color / poll_tex for the -z and +-x
+ * cells, the camera's rotation and -- through the blend of four texels per
+ * pixel -- the JPEG decoder's bytes (tests/test_cubemap_golden.py) --
  * plus hand-derived analytic known-answer tests (tests/test_oracle_kat.py).
- * PARITY UNPINNED for what none of those images shows: cubemap sampling
- * (skybox.rs:64-119), texture coordinates on meshes (mesh.rs:61-77), normals
- * averaged over shared vertices (mesh.rs:208-254), refraction through meshes
- * and cubes; these rest on the known-answer tests and the cited lines.
+ * PARITY UNPINNED for what none of those images shows: the +-y cells of the
+ * cubemap and their flips (skybox.rs:102-116), texture coordinates on meshes
+ * (mesh.rs:61-77), normals averaged over shared vertices (mesh.rs:208-254),
+ * refraction through meshes and cubes; these rest on the known-answer tests
+ * and the cited lines.
  *
  * Every function cites the reference lines it follows.  Rules kept throughout:
  * f64 where the reference is f64, f32 exactly where it is f32, no fused
@@ -442,10 +448,17 @@ Color texture_at(const rt_texture& t, float u, float v) {
     return {0, 0, 0};
 }
 
+/* Deliberate mistakes, for the tests' negative controls only (orc_set_mistake): a test that compares this file with a
+ * render the reference's author made must FAIL when one of these is switched on, or it shows nothing.
+ *   1  cubemap texels taken from the nearest texel instead of the four-tap blend of skybox.rs:70-84
+ *   2  the x = -1 and x = +1 entries of the cubemap's face table (skybox.rs:96-99) exchanged */
+std::atomic<uint32_t> g_mistake{0};
+
 /* skybox.rs:64-86 */
 Color poll_tex(const rt_skybox& sb, uint32_t cell, uint32_t cx, uint32_t cy, float xf, float yf) {
     double x = (double)(cx * cell) + (double)xf * (double)(cell - 1);
     double y = (double)(cy * cell) + (double)yf * (double)(cell - 1);
+    if (g_mistake.load(std::memory_order_relaxed) & 1u) { x = std::floor(x + 0.5); y = std::floor(y + 0.5); }
     auto px = [&](double xx, double yy) -> Color {
         COUNT(texel_cubemap);
         uint32_t xi = as_u32(xx), yi = as_u32(yy);
@@ -482,6 +495,7 @@ Color skybox_ray_color(const Scene& sc, const Ray& ray) {
             else if (normal.y == 1.) { cx = 1; cy = 0; }
             else if (normal.y == -1.) { cx = 1; cy = 2; }
             else { COUNT(would_panic); return {0, 0, 0}; }                         /* unreachable!() :107 */
+            if ((g_mistake.load(std::memory_order_relaxed) & 2u) && (normal.x == 1. || normal.x == -1.) && normal.z != -1.) cx = 2 - cx;
             float u = h.u, v = h.v;
             if (normal.y == 1.) { u = 1.f - h.u; v = 1.f - h.v; }
             else if (normal.y == -1.) { u = h.u; v = 1.f - h.v; }
@@ -726,6 +740,7 @@ std::atomic<uint64_t> g_area_seed{0x9E3779B97F4A7C15ull};
 extern "C" {
 
 void orc_set_area_seed(uint64_t seed) { g_area_seed.store(seed); }
+void orc_set_mistake(uint32_t flags) { g_mistake.store(flags); }
 
 /* scene.rs:220-246 over an explicit pixel list (pixel index i = y*vw + x, the
  * reference's own linear index); pixels == NULL renders 0..n in order. */

@@ -45,6 +45,9 @@ void orc_skybox_ray_color(const rt_skybox* sb, const double* d, uint8_t* out);
 double orc_powi(double a, int b);
 /* area.rs:121 draws from an unseeded generator; the checker's stand-in is seeded, and this sets the seed of later renders */
 void orc_set_area_seed(uint64_t seed);
+/* negative controls of the tests: bit 0 nearest-texel cubemap sampling, bit 1 two cubemap face-table entries exchanged;
+ * 0 (the default) = the reference's behaviour */
+void orc_set_mistake(uint32_t flags);
 
 #ifdef __cplusplus
 }
