@@ -10,7 +10,12 @@ One step = one frame: every rank renders its interleaved 16x16 tiles (rt_render_
 gathered to rank 0 (RCCL) and scattered into the row-major frame (rt_detile).  The scene is resident in HBM before the
 timed region; the frame stays in HBM.  A ray is one Scene::cast_ray_once call of the reference.
 
-The K timed frames are a sequence (the reference's --sequence workload): --frames-in-flight F sets of launches (default
+The K timed frames are a sequence (the reference's --sequence workload, sdl/src/main.rs:70-95, whose frames move with
+`t`): the camera orbits the point it looks at by 0.25 degrees and moves 0.03 % of its distance closer per frame, so every
+frame of the run is a different picture (--still holds the scene's own view instead: the same frame K times).  The warm-up
+renders the stretch of the path BEFORE the timed frames, as a running sequence would have: the level sizes the timed sets
+are queued with were learned from earlier frames, never from themselves (`frames_rendered_twice` counts the sets that
+outgrew them).  --frames-in-flight F sets of launches (default
 2) are in flight per GPU, each frame complete and delivered in order; F = 1 renders them strictly one after the other.
 A set of launches covers --batch B consecutive frames (rt_render_shard_batch): by default half of the K frames -- whole
 frames on one GPU, this rank's shard of them when the frame is sharded over N GPUs -- and at most ten whole frames' worth
@@ -129,6 +134,29 @@ CONFIGS = {"1": (_config1, (1920, 1080)), "2": (_config2, (1920, 1080)), "3": (_
            "4": (_config4, (3840, 2160)), "5a": (_config5a, (7680, 4320)), "5b": (_config5b, (7680, 4320))}
 
 
+def camera_path(base, f, still=False):
+    """Frame f of the benchmark sequence: the base camera moved round the vertical axis through the point it looks at
+    on the ground (or 5 units ahead when it does not look down) by 0.25 degrees per frame, and 0.03 % of its distance
+    nearer per frame (config 4: 0.1 units).  The view direction of camera.rs:55-59 for (yaw, pitch) is
+    (cos p sin y, sin p, -cos p cos y), so the camera keeps looking at the pivot with yaw = atan2(dx, -dz)."""
+    import math
+    from raytracer_amd.scene import Camera
+    if still:
+        return Camera(vw=base.vw, vh=base.vh, origin=tuple(base.origin), yaw=base.yaw, pitch=base.pitch, fov=base.fov)
+    ox, oy, oz = (float(v) for v in base.origin)
+    cp, sp = math.cos(base.pitch), math.sin(base.pitch)
+    reach = min(oy / -sp * cp, 1e4) if sp < -1e-3 and oy > 0 else 5.0          # horizontal distance to the pivot
+    px, pz = ox + reach * math.sin(base.yaw), oz - reach * math.cos(base.yaw)
+    a = math.radians(0.25) * f
+    r = reach * (1.0 - 0.0003) ** f
+    # the camera's place on the circle round the pivot, seen from the pivot
+    bx, bz = ox - px, oz - pz
+    nx, nz = (bx * math.cos(a) - bz * math.sin(a)) * r / reach, (bx * math.sin(a) + bz * math.cos(a)) * r / reach
+    yaw = math.atan2(-nx, nz)
+    return Camera(vw=base.vw, vh=base.vh, origin=(px + nx, oy * r / reach, pz + nz), yaw=yaw if abs(yaw) > 1e-9 else 1e-4,
+                  pitch=base.pitch, fov=base.fov)
+
+
 def default_batch(steps, world, small):
     """Frames per set of launches when --batch is not given: half of the run's frames, at most ten whole frames' worth
     of rays (10 x world shard frames) and at most RT_BATCH_MAX = 64; frames beyond 4K go one per set on one GPU and at
@@ -154,6 +182,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--frames-in-flight", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None, help="frames per set of launches (default: half of the steps, at most ten whole frames' worth of rays)")
+    ap.add_argument("--still", action="store_true", help="every frame through the scene's own camera (the same picture K times) instead of the camera path")
     args = ap.parse_args()
 
     import torch
@@ -214,7 +243,13 @@ def main():
     pipe = rd.FramePipeline(make_context, rank, world, device, depth=depth, batch=batch)
     t_upload = t_upload[0]
     info = ra.desc_info(scene.flatten())
-    camera_of = None     # the sequence: the same view, frame after frame
+    base_cam = scene.camera                          # the scene's own view: frame 0 of the path
+    cursor = [0]                                     # frames of the path rendered so far: every run() continues where the last one ended
+    cam_last = [None]
+
+    def camera_at(f):
+        cam_last[0] = camera_path(base_cam, f, args.still)
+        return cam_last[0]
 
     def sync():
         torch.cuda.synchronize(device)
@@ -229,7 +264,16 @@ def main():
         last["st"], last["frame"] = st, frame
 
     def run(n, cb=keep):
-        return pipe.run(n, cb, camera_of=camera_of)
+        first = cursor[0]
+        cursor[0] += n
+        return pipe.run(n, cb, camera_of=lambda f: camera_at(first + f))
+
+    def twice(stats_list):
+        # rt_stats.respeculated counts per context; set j of a run went to context j % depth
+        lastv = {}
+        for j, x in enumerate(stats_list):
+            lastv[j % depth] = int(x.respeculated)
+        return lastv
 
     # warm-up: every context renders, and every shape of launch set the timed run will use (a last, shorter batch
     # included) has been seen once, so that its level sizes are known (see rt_stats.speculative)
@@ -246,35 +290,46 @@ def main():
     sync()
     ms_alone = (time.perf_counter() - t0) * 1e3 / alone
 
-    run(args.warmup)
+    before = twice(run(max(args.warmup, depth)))      # (every context once more, so that each one's count is known)
     sync()
     t0 = time.perf_counter()
     stats = run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     st, frame = last["st"], last["frame"]
+    last_frame_index = cursor[0] - 1
+    last_cam = camera_path(base_cam, last_frame_index, args.still)
     ms_trace = sum(x.ms_trace for x in stats); ms_shadow = sum(x.ms_shadow for x in stats)
     ms_shade = sum(x.ms_shade for x in stats); ms_resolve = sum(x.ms_resolve for x in stats)
     ms_kernels = sum(x.ms_render for x in stats)
-    n_respeculated = int(stats[-1].respeculated)
+    after = twice(stats)
+    n_respeculated = sum(after[k] - before.get(k, 0) for k in after)
 
-    per = float(st.frames)
-    rays = torch.tensor([round(v / per) for v in (st.rays_primary, st.rays_reflect, st.rays_transmit, st.rays_shadow)], dtype=torch.int64, device=device)
+    # rays of all K timed frames (each set of launches reports the rays of its frames; frames differ along the path)
+    rays = torch.tensor([sum(int(getattr(x, k)) for x in stats) for k in ("rays_primary", "rays_reflect", "rays_transmit", "rays_shadow")],
+                        dtype=torch.int64, device=device)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    rays = [int(x) for x in rays.cpu()]
+    rays_run = [int(x) for x in rays.cpu()]
+    rays = [r / args.steps for r in rays_run]        # per frame, averaged over the run
     elapsed = float(tmax.cpu()[0])
     rays_frame = sum(rays)
     ms_per_step = elapsed * 1e3 / args.steps
-    value = rays_frame * args.steps / elapsed / 1e6
+    value = sum(rays_run) / elapsed / 1e6
+
+    # the untimed legs below, and the CPU leg, look at the LAST timed frame: the scene takes that frame's camera
+    last_cam.vw, last_cam.vh = vw, vh
+    scene.set_camera(last_cam)
 
     # ---- untimed legs on rank 0 of a one-GPU run: end-to-end frames, exclusive kernel durations, instrumented counts
     visits = end_to_end = serial = None
     if rank == 0 and world == 1:
         # (1) Scene::render's own contract: pixels in host memory (scene.rs:220-246) -- rt_render, one frame at a time
         ctx0 = pipe.ctxs[0]
+        ctx0.upload(scene, keep_meshes=True)          # the last timed frame's camera; the meshes stay where they are
+        ctx0.render()
         ctx0.render()
         t0 = time.perf_counter()
         n_e2e = 5
@@ -334,6 +389,7 @@ def main():
         b_alg["GB/s_over_frame_time"] = b_alg["total"] / (ms_per_step * 1e-3) / 1e9
 
         roofline = None
+        roofline_unavailable = None
         if serial and serial["k_shadow_main_avg_launch_ms"] > 0 and args.config == "4":
             dur = serial["k_shadow_main_avg_launch_ms"] * 1e-3          # exclusive, measured in this run
             n_l = serial["k_shadow_main_launches_per_frame"]
@@ -345,39 +401,60 @@ def main():
                                                "the HBM peak and never the bound"}
             fr["bvh_bytes_touched"]["frac"] = fr["bvh_bytes_touched"]["achieved"] / HBM_PEAK_GBS
             traffic = None
-            ipath = os.path.join(ROOT, "profiles", "r2_roofline_inputs.json")
-            if os.path.exists(ipath):
+            stale = None
+            ipath = os.path.join(ROOT, "profiles", "r3_roofline_inputs.json")
+            inp = None
+            if not os.path.exists(ipath):
+                stale = "profiles/r3_roofline_inputs.json is missing (tools/round_profiles.sh writes it)"
+            else:
                 try:
+                    from raytracer_amd._native import source_hash
                     inp = json.load(open(ipath))
-                    if inp.get("workload_cells") == args.cells and inp.get("resolution") == [vw, vh] and inp.get("lights") == args.lights:
-                        k = inp["k_shadow_main"]
-                        traffic = k["hbm_bytes_per_launch"]
-                        fr["hbm"] = {"achieved": traffic / dur / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_launch": traffic,
-                                     "note": "(2 x FETCH_SIZE + WRITE_SIZE) of the counter passes in profiles/, per launch; an upper bound: the counter tallies vector-memory fetches at half and fetches through the scalar cache exactly (profiles/r2_fetch_calibration.json)"}
-                        fr["hbm"]["frac"] = fr["hbm"]["achieved"] / HBM_PEAK_GBS
-                        if "fetch_size_raw_bytes_per_launch" in k:
-                            low = k["fetch_size_raw_bytes_per_launch"] + k.get("write_bytes_per_launch", 0)
-                            fr["hbm"]["per_launch_lower_bound"] = low               # FETCH_SIZE as it reads + WRITE_SIZE
-                            fr["hbm"]["frac_lower_bound"] = low / dur / 1e9 / HBM_PEAK_GBS
-                        busy = k["valu_busy_cycles_per_launch"]         # SQ_ACTIVE_INST_VALU x 4, summed over the chip's SIMDs
-                        peak = SIMDS * CLOCK_GHZ
-                        fr["valu"] = {"achieved": busy / dur / 1e9, "peak": peak, "unit": "G SIMD-cycles/s", "per_launch": busy,
-                                      "valu_instructions_per_launch": k.get("valu_insts_per_launch"),
-                                      "busy_at_measured_clock": k.get("valu_busy_frac_measured_clock"),
-                                      "note": "cycles the vector ALUs are busy (SQ_ACTIVE_INST_VALU x 4) against SIMDs x the 2.4 GHz "
-                                              "spec clock; the clock under this load is lower (busy_at_measured_clock uses GRBM_GUI_ACTIVE)"}
-                        fr["valu"]["frac"] = fr["valu"]["achieved"] / peak
+                    if inp.get("code_sha256") != source_hash():
+                        stale = ("the counter passes in profiles/r3_roofline_inputs.json were taken on another build of the kernels "
+                                 f"(sources then {str(inp.get('code_sha256'))[:12]}, now {source_hash()[:12]}): run tools/round_profiles.sh")
+                    elif not (inp.get("workload_cells") == args.cells and inp.get("resolution") == [vw, vh] and inp.get("lights") == args.lights):
+                        stale = "the counter passes in profiles/r3_roofline_inputs.json are of another workload"
                 except Exception as e:   # a malformed file must not lose the run
-                    fr["inputs_error"] = repr(e)
-            hw = [k for k in ("valu", "hbm") if k in fr] or ["bvh_bytes_touched"]   # (no counter file: the side figure stands in)
-            bound = max(hw, key=lambda k: fr[k]["frac"])
-            roofline = {"bound": bound, "kernel": "k_shadow<false, false, false>", "achieved": fr[bound]["achieved"], "peak": fr[bound]["peak"],
-                        "unit": fr[bound]["unit"], "frac": fr[bound]["frac"], "traffic": traffic,
-                        "avg_launch_ms": serial["k_shadow_main_avg_launch_ms"], "launches_per_frame": n_l,
-                        "share_of_frame_kernel_time": serial["k_shadow_main_avg_launch_ms"] * n_l / serial["ms_per_frame_kernels"],
-                        "roofs": fr,
-                        "note": "launch duration: HIP events around the kernel on its own stream in a context whose kernels run one "
-                                "after the other (this run); bound = the hardware roof (valu, hbm) with the largest fraction"}
+                    stale = "profiles/r3_roofline_inputs.json could not be read: " + repr(e)
+            if not stale:
+                k = inp["k_shadow_main"]
+                traffic = k["hbm_bytes_per_launch"]
+                fr["hbm"] = {"achieved": traffic / dur / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_launch": traffic,
+                             "note": "(2 x FETCH_SIZE + WRITE_SIZE) of the counter passes in profiles/, per launch; an upper bound: the counter tallies vector-memory fetches at half and fetches through the scalar cache exactly (profiles/r2_fetch_calibration.json)"}
+                fr["hbm"]["frac"] = fr["hbm"]["achieved"] / HBM_PEAK_GBS
+                if "fetch_size_raw_bytes_per_launch" in k:
+                    low = k["fetch_size_raw_bytes_per_launch"] + k.get("write_bytes_per_launch", 0)
+                    fr["hbm"]["per_launch_lower_bound"] = low               # FETCH_SIZE as it reads + WRITE_SIZE
+                    fr["hbm"]["frac_lower_bound"] = low / dur / 1e9 / HBM_PEAK_GBS
+                busy = k["valu_busy_cycles_per_launch"]         # SQ_ACTIVE_INST_VALU x 4, summed over the chip's SIMDs
+                peak = SIMDS * CLOCK_GHZ
+                fr["valu"] = {"achieved": busy / dur / 1e9, "peak": peak, "unit": "G SIMD-cycles/s", "per_launch": busy,
+                              "valu_instructions_per_launch": k.get("valu_insts_per_launch"),
+                              "busy_at_measured_clock": k.get("valu_busy_frac_measured_clock"),
+                              "note": "cycles the vector ALUs are busy (SQ_ACTIVE_INST_VALU x 4) against SIMDs x the 2.4 GHz "
+                                      "spec clock; the clock under this load is lower (busy_at_measured_clock uses GRBM_GUI_ACTIVE)"}
+                fr["valu"]["frac"] = fr["valu"]["achieved"] / peak
+                # how much of that is a ray's arithmetic: the share of the 64 lanes that is live while the vector ALUs
+                # are busy, and the useful fraction that follows; the scalar unit beside it
+                fr["valu"]["valu_lane_utilisation"] = k.get("valu_lane_utilisation")
+                if k.get("valu_lane_utilisation"):
+                    fr["valu"]["frac_live_lanes"] = fr["valu"]["frac"] * k["valu_lane_utilisation"]
+                fr["salu_busy"] = k.get("salu_busy")
+                bound = max(("valu", "hbm"), key=lambda r: fr[r]["frac"])
+                roofline = {"bound": bound, "kernel": "k_shadow<false, false, false>", "achieved": fr[bound]["achieved"], "peak": fr[bound]["peak"],
+                            "unit": fr[bound]["unit"], "frac": fr[bound]["frac"], "traffic": traffic,
+                            "avg_launch_ms": serial["k_shadow_main_avg_launch_ms"], "launches_per_frame": n_l,
+                            "share_of_frame_kernel_time": serial["k_shadow_main_avg_launch_ms"] * n_l / serial["ms_per_frame_kernels"],
+                            "valu_lane_utilisation": k.get("valu_lane_utilisation"), "salu_busy": k.get("salu_busy"),
+                            "roofs": fr,
+                            "note": "launch duration: HIP events around the kernel on its own stream in a context whose kernels run one "
+                                    "after the other (this run); bound = the hardware roof (valu, hbm) with the largest fraction; "
+                                    "counters: profiles/r3_roofline_inputs.json, taken on this build of the kernels (source hash checked)"}
+            else:
+                # no roofline from counters of another build: the line says why, and keeps what this run measured itself
+                roofline_unavailable = {"reason": stale, "kernel": "k_shadow<false, false, false>",
+                                        "avg_launch_ms": serial["k_shadow_main_avg_launch_ms"], "bvh_bytes_touched": fr["bvh_bytes_touched"]}
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -396,7 +473,11 @@ def main():
             "ms_phase_rank0": {"trace": ms_trace / args.steps, "shadow": ms_shadow / args.steps, "spawn+light": ms_shade / args.steps,
                                "resolve": ms_resolve / args.steps},
             "frames_rendered_twice": n_respeculated,
+            "sequence": ("still: the scene's own view for every frame" if args.still else
+                         f"camera path: 0.25 degrees round the point looked at and 0.03 % nearer per frame; timed frames {last_frame_index - args.steps + 1}..{last_frame_index} "
+                         "of the path, level sizes learned from the frames before them; parity and the untimed legs on the last frame"),
             "roofline": roofline,
+            "roofline_unavailable": roofline_unavailable,
             "kernels_one_after_the_other": serial,
             "reference_walk_bytes_per_frame": b_alg,
             "gpu_visits_per_frame": visits,

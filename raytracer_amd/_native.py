@@ -212,6 +212,21 @@ HOST_SYMBOLS = [
 ]
 
 
+def source_hash():
+    """sha256 over the device code's sources (csrc/*.h, csrc/*.hip and include/rtgpu.h: names and bytes, in name order).
+    Profiles record it, so that counters measured on one build of the kernels are not read as another build's."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    files = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".hip")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "rtgpu.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 class RtError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"rtgpu error {code}: {msg}")

@@ -385,6 +385,20 @@ class LoadedScene:
     def flatten(self):
         return N.host().rth_desc_get(self._h)
 
+    @property
+    def camera(self):
+        """the stored description's camera (rt_camera is the first member of rt_scene_desc)"""
+        c = N.RtCamera.from_address(self.flatten())
+        return Camera(vw=c.vw, vh=c.vh, origin=tuple(c.origin), yaw=c.yaw, pitch=c.pitch, fov=c.fov)
+
+    def set_camera(self, camera):
+        """moves the camera of the stored description; the frame size stays the description's"""
+        c = N.RtCamera.from_address(self.flatten())
+        c.origin = (C.c_double * 3)(*[float(x) for x in camera.origin])
+        c.yaw, c.pitch, c.fov = float(camera.yaw), float(camera.pitch), float(camera.fov)
+        c.chf = N.host().rth_camera_chf(float(camera.fov))
+        return self
+
 
 class SdlScene:
     """A scene built by the scene description language of the reference (sdl/src/main.rs:49-53).
