@@ -1407,6 +1407,27 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
     return RT_OK;
 }
 
+// The caller's frame buffer is usually fresh from its allocator (scene.rs:220-246 returns a new Vec per frame): pages the
+// process has never touched, each of which costs a page fault when the frame's bytes arrive -- at 8K (99.5 MB, 24,000
+// pages) more time than the copy over the link.  The faults do not have to wait for the frame: host threads touch the
+// buffer's pages (one byte per page; the buffer is an output, whatever it held is overwritten) while the GPU renders.
+struct Prefault {
+    std::vector<std::thread> th;
+    void start(void* dst, size_t bytes, uint32_t n_threads) {
+        const size_t PAGE = 4096;
+        if (!dst || bytes < ((size_t)8 << 20) || n_threads == 0) return;
+        volatile unsigned char* p = static_cast<volatile unsigned char*>(dst);
+        const size_t pages = (bytes + PAGE - 1) / PAGE;
+        const size_t per = (pages + n_threads - 1) / n_threads;
+        for (uint32_t t = 0; t < n_threads; t++) {
+            const size_t a = std::min(pages, t * per), b = std::min(pages, a + per);
+            if (a < b) th.emplace_back([=]() { for (size_t k = a; k < b; k++) { const size_t off = k * PAGE; p[off < bytes ? off : bytes - 1] = 0; } });
+        }
+    }
+    void join() { for (auto& t : th) t.join(); th.clear(); }
+    ~Prefault() { join(); }
+};
+
 // A finished frame from device memory into the caller's (pageable) buffer, after whatever is queued on the context's
 // stream.  hipMemcpy into pageable memory stages through pinned memory chunk by chunk with one host thread behind it
 // (about 18 GB/s here, less into pages the caller has never touched); this does the same with the staging buffer its
@@ -1480,6 +1501,8 @@ int rt_render(rt_ctx* c, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* stat
     auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t px = (size_t)c->vw * (size_t)c->vh;
+    Prefault touch;
+    touch.start(rgb_out, px * 3, c->copy_threads);
     const int64_t slots = rt_shard_pixels(c->vw, c->vh, 0, 1);
     int rc;
     if ((rc = ensure_buf(c, &c->d_out, &c->d_out_cap, px * 3)) != RT_OK) return rc;
@@ -1496,6 +1519,7 @@ int rt_render(rt_ctx* c, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* stat
                            static_cast<const uint32_t*>(c->d_ids), static_cast<uint32_t*>(c->d_ids2), (uint32_t)slots, map);
         HIP_TRY(c, hipMemcpyAsync(prim_id_out, c->d_ids2, px * 8, hipMemcpyDeviceToHost, c->stream));
     }
+    touch.join();
     if ((rc = copy_frame_to_host(c, rgb_out, c->d_out, px * 3)) != RT_OK) return rc;
     HIP_TRY(c, hipGetLastError());
     st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1867,6 +1891,8 @@ static int multi_render(rt_ctx* head, rt_multi& M, uint32_t n_frames, const rt_c
     }
     HIP_TRY(head, hipSetDevice(head->device));
     int rc;
+    Prefault touch;
+    touch.start(rgb_out, (size_t)plan.frame_bytes_rgb * n_frames, head->copy_threads);
     if ((rc = ensure_buf(head, &M.gath_rgb, &M.gath_rgb_cap, (size_t)plan.gathered_bytes_rgb)) != RT_OK) return rc;
     if (prim_id_out && (rc = ensure_buf(head, &M.gath_ids, &M.gath_ids_cap, (size_t)plan.gathered_bytes_ids)) != RT_OK) return rc;
     if ((rc = ensure_buf(head, &M.frames, &M.frames_cap, (size_t)plan.frame_bytes_rgb * n_frames)) != RT_OK) return rc;
@@ -1895,6 +1921,7 @@ static int multi_render(rt_ctx* head, rt_multi& M, uint32_t n_frames, const rt_c
         if ((rc = rt_detile_frames(head, M.gath_ids, n, n_frames, plan.slots_per_shard, 8, head->d_ids2)) != RT_OK) return rc;
         HIP_TRY(head, hipMemcpyAsync(prim_id_out, head->d_ids2, (size_t)head->vw * head->vh * 8 * n_frames, hipMemcpyDeviceToHost, head->stream));
     }
+    touch.join();
     if ((rc = copy_frame_to_host(head, rgb_out, M.frames, (size_t)plan.frame_bytes_rgb * n_frames)) != RT_OK) return rc;
     HIP_TRY(head, hipGetLastError());
     if (stats_out) {

@@ -633,20 +633,33 @@ def test_speculative_frames_equal_measured_ones_and_fall_back_when_a_level_outgr
         for r, i, s in ((r1, i1, s1), (r2, i2, s2)):
             assert np.array_equal(r, o_rgb) and np.array_equal(i, o_ids)
             assert ray_counts(s) == ray_counts(o_st) and list(s.rays_per_level) == list(o_st.rays_per_level)
-        # same size, far fewer secondary rays, then far more: the second change overflows the learned room
+        # the same scene with the camera turned to the sky, then back (a sequence: meshes kept): far fewer secondary
+        # rays, then far more, and the second change overflows the room learned from the frame before
+        cam = a.camera
+        a.set_camera(ra.Camera(vw=160, vh=120, origin=cam.origin, yaw=cam.yaw, pitch=1.4, fov=cam.fov))
+        ctx.upload(a, keep_meshes=True)
+        rf, _, sf = ctx.render()
+        assert sf.speculative == 1 and sf.respeculated == 0 and sf.rays < s1.rays // 4
+        assert np.array_equal(rf, oracle.render(a, 0)[0])
+        a.set_camera(cam)
+        ctx.upload(a, keep_meshes=True)
+        r3, i3, s3 = ctx.render(ids=True)
+        assert s3.respeculated == 1 and s3.speculative == 0
+        assert np.array_equal(r3, o_rgb) and np.array_equal(i3, o_ids) and ray_counts(s3) == ray_counts(o_st)
+        r4, _, s4 = ctx.render()
+        assert s4.speculative == 1 and s4.respeculated == 1 and np.array_equal(r4, o_rgb)
+        # another scene of the same frame size does not inherit this one's level sizes: its first frame is measured
+        # (it would otherwise be queued with the wrong room and, outgrowing it, be rendered twice)
         few = ra.Scene()
         few.set_camera(ra.Camera(vw=160, vh=120))
         few.add(ra.Sphere((0., 0., -5.), 0.5, ra.Material(reflectiveness=0.3)))
         few.add_light(ra.Sun())
         ctx.upload(few)
         rf, _, sf = ctx.render()
-        assert np.array_equal(rf, oracle.render(few, 0)[0]) and sf.respeculated == 0
+        assert sf.speculative == 0 and sf.respeculated == 1 and np.array_equal(rf, oracle.render(few, 0)[0])
         ctx.upload(a)
-        r3, i3, s3 = ctx.render(ids=True)
-        assert s3.respeculated == 1 and s3.speculative == 0
-        assert np.array_equal(r3, o_rgb) and np.array_equal(i3, o_ids) and ray_counts(s3) == ray_counts(o_st)
-        r4, _, s4 = ctx.render()
-        assert s4.speculative == 1 and s4.respeculated == 1 and np.array_equal(r4, o_rgb)
+        r5, _, s5 = ctx.render()
+        assert s5.speculative == 0 and s5.respeculated == 1 and np.array_equal(r5, o_rgb)
     monkeypatch.setenv("RTGPU_SYNC_LEVELS", "1")
     with ra.Context(0) as ctx:
         ctx.upload(a)
