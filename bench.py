@@ -134,6 +134,12 @@ CONFIGS = {"1": (_config1, (1920, 1080)), "2": (_config2, (1920, 1080)), "3": (_
            "4": (_config4, (3840, 2160)), "5a": (_config5a, (7680, 4320)), "5b": (_config5b, (7680, 4320))}
 
 
+# The roofline legs (the dominant kernel timed alone, the instrumented frame) and the counter passes kept under profiles/
+# (tools/prof_frame.py) all render THIS frame of the camera path, whatever --steps and --warmup are: per-launch counters of
+# one view divided by the launch duration of another would be no fraction of anything.
+ROOFLINE_FRAME = 100
+
+
 def camera_path(base, f, still=False):
     """Frame f of the benchmark sequence: the base camera moved round the vertical axis through the point it looks at
     on the ground (or 5 units ahead when it does not look down) by 0.25 degrees per frame, and 0.03 % of its distance
@@ -339,7 +345,11 @@ def main():
         pipe.close()
         pipe = None
         # (2) the dominant kernel alone: a context whose kernels run one after the other on one stream, so that the
-        #     HIP events around k_shadow<false, false, false> (on that stream) bracket nothing else
+        #     HIP events around k_shadow<false, false, false> (on that stream) bracket nothing else.  Frame ROOFLINE_FRAME
+        #     of the path: the view the counter passes under profiles/ were taken on.
+        roof_cam = camera_path(base_cam, ROOFLINE_FRAME, args.still)
+        roof_cam.vw, roof_cam.vh = vw, vh
+        scene.set_camera(roof_cam)
         os.environ["RTGPU_SERIAL"] = "1"
         sctx = ra.Context(local_rank)
         sctx.upload(scene)
@@ -364,6 +374,7 @@ def main():
             del os.environ["RTGPU_COUNT_VISITS"]
             return cst
         cst, shst = instrumented("1"), instrumented("shadow")
+        scene.set_camera(last_cam)                    # (the CPU leg below looks at the last timed frame again)
         visits = {"lane_node_visits": int(cst.nodes_visited), "lane_tri_tests": int(cst.tris_tested),
                   # wave_tri_steps: triangle records fetched per wave by the closest-hit packets, and rounds of 64
                   # (ray, leaf) pairs tested by the shadow packets (whose lanes fetch their own triangles)
@@ -440,7 +451,8 @@ def main():
                 fr["valu"]["valu_lane_utilisation"] = k.get("valu_lane_utilisation")
                 if k.get("valu_lane_utilisation"):
                     fr["valu"]["frac_live_lanes"] = fr["valu"]["frac"] * k["valu_lane_utilisation"]
-                fr["salu_busy"] = k.get("salu_busy")
+                fr["salu_busy"] = k.get("salu_busy")          # wave-cycles on scalar instructions per SIMD-cycle
+                fr["salu_insts_per_cu_cycle"] = k.get("salu_insts_per_cu_cycle")
                 bound = max(("valu", "hbm"), key=lambda r: fr[r]["frac"])
                 roofline = {"bound": bound, "kernel": "k_shadow<false, false, false>", "achieved": fr[bound]["achieved"], "peak": fr[bound]["peak"],
                             "unit": fr[bound]["unit"], "frac": fr[bound]["frac"], "traffic": traffic,
@@ -448,6 +460,7 @@ def main():
                             "share_of_frame_kernel_time": serial["k_shadow_main_avg_launch_ms"] * n_l / serial["ms_per_frame_kernels"],
                             "valu_lane_utilisation": k.get("valu_lane_utilisation"), "salu_busy": k.get("salu_busy"),
                             "roofs": fr,
+                            "frame_of_the_path": "the scene's own view" if args.still else ROOFLINE_FRAME,
                             "note": "launch duration: HIP events around the kernel on its own stream in a context whose kernels run one "
                                     "after the other (this run); bound = the hardware roof (valu, hbm) with the largest fraction; "
                                     "counters: profiles/r3_roofline_inputs.json, taken on this build of the kernels (source hash checked)"}

@@ -2,6 +2,8 @@
 
 usage: fuzz_parity.py [n_scenes] [first_seed]      (FUZZ_RICH=1: image textures, larger meshes, more objects;
                                                     FUZZ_SHARDS=1: every frame also rendered as 2-9 shards and reassembled;
+                                                    FUZZ_MULTI=1: every scene also through a context over 2-5 "devices" (all of them
+                                                    GPU 0: rt_ctx_create_multi, rt_render and a 3-frame rt_render_frames);
                                                     FUZZ_AREA=1: 1-2 area lights per scene, spheres and rectangles of 0-9 sample
                                                     points with short and long reach, and a seed of its own per scene)
 Every scene draws its own mix of objects (0-40 spheres and boxes, so both the linear object list and the object tree
@@ -99,7 +101,9 @@ def main():
     rich = bool(int(os.environ.get("FUZZ_RICH", "0")))
     shards = bool(int(os.environ.get("FUZZ_SHARDS", "0")))
     area = bool(int(os.environ.get("FUZZ_AREA", "0")))
+    multi = bool(int(os.environ.get("FUZZ_MULTI", "0")))
     bad = 0
+    mctx = {k: ra.Context(devices=[0] * k) for k in range(2, 6)} if multi else {}
     with ra.Context(0) as ctx:
         for seed in range(first, first + n):
             s, (vw, vh) = random_scene(seed, rich, area)
@@ -122,6 +126,34 @@ def main():
                 if not (np.array_equal(frame.cpu().numpy().reshape(vh, vw, 3), rgb) and sh_rays == st.rays):
                     bad += 1
                     print(f"seed {seed}: {vw}x{vh} SHARD MISMATCH with {n_sh} shards", flush=True)
+            if multi:
+                # the same frame through one context over several shards-on-one-GPU; then three frames of a camera
+                # path as one set of launches against the same frames rendered one by one
+                m = mctx[2 + seed % 4]
+                if area:
+                    m.set_area_seed(area_seed)
+                m.upload(s)
+                m_rgb, m_ids, m_st = m.render(ids=True)
+                if not (np.array_equal(m_rgb, rgb) and np.array_equal(m_ids, ids) and m_st.rays == st.rays):
+                    bad += 1
+                    print(f"seed {seed}: {vw}x{vh} MULTI MISMATCH over {m.n_devices} devices", flush=True)
+                cam = s.camera
+                cams = [ra.Camera(vw=vw, vh=vh, origin=tuple(float(x) + 0.2 * f for x in cam.origin), yaw=cam.yaw + 0.03 * f, pitch=cam.pitch - 0.02 * f, fov=cam.fov)
+                        for f in range(3)]
+                fr, fi, fst = m.render_frames(cams, ids=True)
+                tot = 0
+                for f, c in enumerate(cams):
+                    s.set_camera(c)
+                    ctx.upload(s)
+                    one, one_ids, one_st = ctx.render(ids=True)
+                    tot += one_st.rays
+                    if not (np.array_equal(fr[f], one) and np.array_equal(fi[f], one_ids)):
+                        bad += 1
+                        print(f"seed {seed}: {vw}x{vh} MULTI FRAMES MISMATCH frame {f} over {m.n_devices} devices", flush=True)
+                if tot != fst.rays:
+                    bad += 1
+                    print(f"seed {seed}: MULTI FRAMES ray count {fst.rays} != {tot}", flush=True)
+                s.set_camera(cam)
             o_rgb, o_ids, o_st, oc = oracle.render(s, 0)
             same_rgb = np.array_equal(rgb, o_rgb)
             same_ids = np.array_equal(ids, o_ids)
@@ -134,6 +166,8 @@ def main():
                 print(f"seed {seed}: {vw}x{vh} MISMATCH rgb {same_rgb} ({diff} pixels) ids {same_ids} rays {same_rays} panic {oc.would_panic}", flush=True)
             elif (seed - first) % 10 == 0:
                 print(f"seed {seed}: {vw}x{vh} ok, {st.rays} rays", flush=True)
+    for m in mctx.values():
+        m.close()
     print(f"{n} scenes, {bad} mismatches", flush=True)
     sys.exit(1 if bad else 0)
 

@@ -38,10 +38,12 @@ cams = lambda first: ctx.camera_array([bench.camera_path(base, first + f) for f 
 ctx.render_frames(cams(0))                      # measured set: level sizes learned
 ctx.render_frames(cams(per_set))                # first speculative set, buffers in place
 rays = 0
+ms_kernels = 0.0
 t0 = time.perf_counter()
 for k in range(sets):
     frames, _, st = ctx.render_frames(cams((k + 2) * per_set))
     rays += st.rays
+    ms_kernels += st.ms_render
 dt = time.perf_counter() - t0
 twice = int(st.respeculated)
 last = bench.camera_path(base, (sets + 2) * per_set - 1)
@@ -53,5 +55,6 @@ with ra.Context(devices[0]) as one:
 same = bool(np.array_equal(frames[-1], want))
 ctx.close()
 print(json.dumps({"metric": "Mrays/s (primary+secondary), pixels in host memory", "value": rays / dt / 1e6, "n_gpus": len(devices), "devices": devices,
-                  "ms_per_frame": dt * 1e3 / (sets * per_set), "frames_per_set": per_set, "sets": sets, "resolution": [vw, vh],
+                  "ms_per_frame": dt * 1e3 / (sets * per_set),
+                  "ms_per_frame_kernels_slowest_device": ms_kernels / (sets * per_set), "frames_per_set": per_set, "sets": sets, "resolution": [vw, vh],
                   "upload_s": t_upload, "frames_rendered_twice": twice, "last_frame_equals_one_device_render": same}))

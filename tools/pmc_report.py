@@ -25,5 +25,5 @@ for k, v in agg.items():
         g5 = q.get("GRBM_GUI_ACTIVE", 0) / 8
         print(f"    -> live lanes per busy VALU cycle {q['SQ_THREAD_CYCLES_VALU']/q['SQ_ACTIVE_INST_VALU']:.1f} of 64 "
               f"(lane utilisation {q['SQ_THREAD_CYCLES_VALU']/q['SQ_ACTIVE_INST_VALU']/64:.2%}); "
-              f"scalar unit busy {q['SQ_ACTIVE_INST_SCA']*4/256/g5 if g5 else 0:.2%} of CU-cycles (SQ_ACTIVE_INST_SCA x 4 / 256 CUs), "
-              f"SALU issue cycles {q['SQ_INST_CYCLES_SALU']*4/256/g5 if g5 else 0:.2%}")
+              f"wave-cycles on scalar instructions {q['SQ_ACTIVE_INST_SCA']*4/1024/g5 if g5 else 0:.2%} of SIMD-cycles (SQ_ACTIVE_INST_SCA x 4 / 1024 SIMDs), "
+              f"scalar ALU instructions per CU-cycle {q['SQ_INSTS_SALU']/256/g5 if g5 else 0:.2f}")

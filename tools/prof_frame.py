@@ -1,4 +1,6 @@
 """Renders a few frames of the benchmark scene with nothing else around them: the program to put under rocprofv3.
+The view is frame bench.ROOFLINE_FRAME of bench.py's camera path -- the frame whose launches bench.py times for its
+roofline -- unless STILL=1 asks for the scene's own camera.
 SHARDS=n in the environment renders shard 0 of n instead of the whole frame."""
 import os
 import sys
@@ -11,6 +13,14 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 cells = int(sys.argv[2]) if len(sys.argv) > 2 else 708
 w, h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (3840, 2160)
 s = scenes.synthetic_terrain_scene(w, h, cells=cells)
+if not os.environ.get("STILL"):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cam = bench.camera_path(s.camera, bench.ROOFLINE_FRAME)
+    cam.vw, cam.vh = w, h
+    s.set_camera(cam)
 ctx = ra.Context(0)
 ctx.upload(s)
 shards = int(os.environ.get("SHARDS", "1"))

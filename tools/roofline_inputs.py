@@ -34,6 +34,7 @@ per = {k: agg[k] / launches[k] for k in agg}
 cyc_xcd = per.get("GRBM_GUI_ACTIVE", 0) / 8
 out = {
     "workload_cells": 708, "resolution": [3840, 2160], "lights": 8, "n_gpus": 1,
+    "view": "frame ROOFLINE_FRAME of bench.py's camera path (tools/prof_frame.py)",
     "code_sha256": source_hash(),
     "source": f"tools/pmc.sh {pmc} + tools/traffic.sh {traffic} (rocprofv3 --pmc, kernels serialised by the profiler)",
     "k_shadow_main": {
@@ -49,8 +50,11 @@ out = {
         # of the cycles the vector ALUs are busy, the share of their 64 lanes that is live (SQ_THREAD_CYCLES_VALU /
         # (SQ_ACTIVE_INST_VALU x 64), one counter pass); the scalar unit's busy cycles per CU-cycle
         "valu_lane_utilisation": lane["SQ_THREAD_CYCLES_VALU"] / lane["SQ_ACTIVE_INST_VALU"] / 64 if lane.get("SQ_ACTIVE_INST_VALU") else None,
-        "salu_busy": lane["SQ_ACTIVE_INST_SCA"] * 4 / 256 / (lane["GRBM_GUI_ACTIVE"] / 8) if lane.get("GRBM_GUI_ACTIVE") else None,
-        "salu_issue_cycles_frac": lane["SQ_INST_CYCLES_SALU"] * 4 / 256 / (lane["GRBM_GUI_ACTIVE"] / 8) if lane.get("GRBM_GUI_ACTIVE") else None,
+        # the scalar side: wave-cycles spent on scalar ALU / scalar memory instructions per SIMD-cycle (SQ_ACTIVE_INST_SCA x 4
+        # over 1024 SIMDs x the XCD's busy cycles: a SIMD issues for one wave at a time), and scalar ALU instructions per
+        # CU-cycle (a CU's one scalar unit takes at most one per cycle)
+        "salu_busy": lane["SQ_ACTIVE_INST_SCA"] * 4 / 1024 / (lane["GRBM_GUI_ACTIVE"] / 8) if lane.get("GRBM_GUI_ACTIVE") else None,
+        "salu_insts_per_cu_cycle": lane["SQ_INSTS_SALU"] / 256 / (lane["GRBM_GUI_ACTIVE"] / 8) if lane.get("GRBM_GUI_ACTIVE") else None,
         "fetch_size_raw_bytes_per_launch": per.get("FETCH_SIZE", 0) * 1024, "write_bytes_per_launch": per.get("WRITE_SIZE", 0) * 1024,
         "hbm_bytes_per_launch": (2 * per.get("FETCH_SIZE", 0) + per.get("WRITE_SIZE", 0)) * 1024,
     },
