@@ -137,7 +137,7 @@ CONFIGS = {"1": (_config1, (1920, 1080)), "2": (_config2, (1920, 1080)), "3": (_
 # The roofline legs (the dominant kernel timed alone, the instrumented frame) and the counter passes kept under profiles/
 # (tools/prof_frame.py) all render THIS frame of the camera path, whatever --steps and --warmup are: per-launch counters of
 # one view divided by the launch duration of another would be no fraction of anything.
-ROOFLINE_FRAME = 100
+ROOFLINE_FRAME = 20
 
 
 def camera_path(base, f, still=False):
@@ -250,7 +250,10 @@ def main():
     t_upload = t_upload[0]
     info = ra.desc_info(scene.flatten())
     base_cam = scene.camera                          # the scene's own view: frame 0 of the path
-    cursor = [0]                                     # frames of the path rendered so far: every run() continues where the last one ended
+    # Where on the path the next run() starts: every run() continues where the last one ended, and the warm-up runs
+    # below count up to 0, so that the timed frames are frames 0 .. K-1 of the path -- the sequence starts at the
+    # scene's own view -- and what precedes them is the stretch of the path that leads there.
+    cursor = [0]
     cam_last = [None]
 
     def camera_at(f):
@@ -283,6 +286,8 @@ def main():
 
     # warm-up: every context renders, and every shape of launch set the timed run will use (a last, shorter batch
     # included) has been seen once, so that its level sizes are known (see rt_stats.speculative)
+    alone = 5
+    cursor[0] = -(max(args.warmup, depth * batch) + (args.steps if batch > 1 else 0) + 3 + alone + max(args.warmup, depth))
     run(max(args.warmup, depth * batch))
     if batch > 1:
         run(args.steps)
@@ -290,13 +295,13 @@ def main():
         run(1)
     sync()
     t0 = time.perf_counter()
-    alone = 5
     for _ in range(alone):
         run(1)
     sync()
     ms_alone = (time.perf_counter() - t0) * 1e3 / alone
 
     before = twice(run(max(args.warmup, depth)))      # (every context once more, so that each one's count is known)
+    assert cursor[0] == 0
     sync()
     t0 = time.perf_counter()
     stats = run(args.steps)

@@ -422,7 +422,9 @@ struct Visits { uint32_t nodes, tris; uint32_t wnodes, wtris; uint32_t units; };
 // Traversal stack: (node reference, entry distance) pairs.  The first RT_LDS_STACK entries of every lane live
 // in LDS, laid out [entry][lane] so that a wave's push or pop touches consecutive 8-byte words (no bank
 // conflicts); deeper entries spill to private memory.
+#ifndef RT_BLOCK_DIM
 #define RT_BLOCK_DIM 256
+#endif
 __shared__ uint2 rt_lds_stack[RT_LDS_STACK * RT_BLOCK_DIM];
 // push/pop on plain locals (sp, spill): kept out of any struct so that the stack pointer stays in a register.
 // The spill array is volatile so that the compiler keeps its (cold) accesses apart from the LDS ones instead
