@@ -733,6 +733,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_ids_rowmajor(const DScene* Sp, con
     out[2 * o] = compact[2 * (size_t)i]; out[2 * o + 1] = compact[2 * (size_t)i + 1];
 }
 
+// A finished frame out of device memory into host memory the device can write (the library's pinned staging buffer),
+// by the device itself: every workgroup moves RT_COPY_BLOCK bytes as 16-byte words and then raises its flag -- a word of
+// its own in host memory, stored with release semantics at system scope, so that a host thread that sees the flag
+// sees the bytes.  Host threads move a block's bytes on into the caller's buffer as soon as its flag is up: no copy
+// commands, no events, nothing of the runtime between the last kernel of the frame and the first byte in host memory.
+#define RT_COPY_BLOCK 32768u
+__global__ __launch_bounds__(256) void k_copy_out(const uint8_t* src, uint8_t* dst_host, unsigned long long bytes, unsigned int* flags) {
+    const unsigned long long base = (unsigned long long)blockIdx.x * RT_COPY_BLOCK;
+    const unsigned long long end = bytes < base + RT_COPY_BLOCK ? bytes : base + RT_COPY_BLOCK;
+    for (unsigned long long off = base + threadIdx.x * 16ull; off + 16ull <= end; off += 256ull * 16ull)
+        *reinterpret_cast<uint4*>(dst_host + off) = *reinterpret_cast<const uint4*>(src + off);
+    const unsigned long long tail = end & ~15ull;       // (only the last block can end off a 16-byte boundary)
+    if (tail + threadIdx.x < end) dst_host[tail + threadIdx.x] = src[tail + threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&flags[blockIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Gathered compact shard buffers -> row-major images (rt_detile, rt_detile_frames).  Layout of `gathered`:
 // [shard][frame][slot], every (shard, frame) run padded to slots_per_shard slots; image f starts at f * vw * vh elements.
 __global__ __launch_bounds__(RT_BLOCK) void k_detile(const uint8_t* gathered, uint8_t* images, int32_t vw, int32_t vh, uint32_t n_shards, uint32_t n_frames,

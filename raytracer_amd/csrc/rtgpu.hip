@@ -105,7 +105,7 @@ struct rt_ctx {
     DCounters* hcounters = nullptr;   // pinned
     void* d_out = nullptr; size_t d_out_cap = 0;      // rgb staging for rt_render
     void* h_stage = nullptr; size_t h_stage_cap = 0;  // pinned host staging for rt_render's copy of the frame (copy_frame_to_host)
-    std::vector<hipEvent_t> stage_ev;                 // one per chunk of that copy
+    unsigned int* h_flags = nullptr;                  // pinned: one word per block of that copy, raised by the device when the block has landed
     uint32_t copy_threads = 4;                        // RTGPU_COPY_THREADS: host threads that move the chunks on (0: one plain hipMemcpy)
     void* d_ids = nullptr; size_t d_ids_cap = 0;      // compact ids
     void* d_ids2 = nullptr; size_t d_ids2_cap = 0;    // row-major ids
@@ -1106,7 +1106,7 @@ void rt_ctx_destroy(rt_ctx* c) {
     for (auto ss : c->side) if (ss) (void)hipStreamDestroy(ss);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
-    for (auto ev : c->stage_ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->h_flags) (void)hipHostFree(c->h_flags);
     if (c->d_ids) (void)hipFree(c->d_ids);
     if (c->d_ids2) (void)hipFree(c->d_ids2);
     if (c->d_cams) (void)hipFree(c->d_cams);
@@ -1429,41 +1429,59 @@ struct Prefault {
 };
 
 // A finished frame from device memory into the caller's (pageable) buffer, after whatever is queued on the context's
-// stream.  hipMemcpy into pageable memory stages through pinned memory chunk by chunk with one host thread behind it
-// (about 18 GB/s here, less into pages the caller has never touched); this does the same with the staging buffer its
-// own and several threads moving the chunks on as they land, so that the copy runs at the link's rate.  Returns with
-// the bytes in place and the stream idle.
+// stream.  A plain hipMemcpy into pageable memory stages through pinned memory with one host thread behind it (about
+// 18 GB/s here); chunked asynchronous copies with an event each depend on the runtime's version (ROCm 7.2: 130 us per
+// copy-and-event pair, 3.9 ms for a 4K frame; the runtime PyTorch 2.10 brings along: 0.8 ms).  So the device moves the
+// bytes itself: k_copy_out writes the frame into the library's pinned staging buffer, raising one flag per 32 KB, and
+// host threads move each block on into the caller's buffer as its flag comes up.  Returns with the bytes in place and
+// the stream idle.
 static int copy_frame_to_host(rt_ctx* c, void* dst, const void* d_src, size_t bytes) {
-    const size_t CHUNK = (size_t)1 << 20;
-    if (c->copy_threads == 0 || bytes < 4 * CHUNK) {
+    if (c->copy_threads == 0 || bytes < ((size_t)4 << 20)) {
         HIP_TRY(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         return RT_OK;
     }
+    const size_t n_blocks = (bytes + RT_COPY_BLOCK - 1) / RT_COPY_BLOCK;
     if (c->h_stage_cap < bytes) {
         if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_cap = 0; }
-        if (hipHostMalloc(&c->h_stage, bytes, hipHostMallocDefault) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipHostMalloc failed for the frame's staging buffer");
+        if (c->h_flags) { (void)hipHostFree(c->h_flags); c->h_flags = nullptr; }
+        // (coherent: what the device writes is visible to the host after the device's system-scope release)
+        if (hipHostMalloc(&c->h_stage, bytes, hipHostMallocCoherent) != hipSuccess ||
+            hipHostMalloc((void**)&c->h_flags, n_blocks * sizeof(unsigned int), hipHostMallocCoherent) != hipSuccess)
+            return fail(c, RT_ERR_NOMEM, "hipHostMalloc failed for the frame's staging buffer");
         c->h_stage_cap = bytes;
     }
-    const size_t n_chunks = (bytes + CHUNK - 1) / CHUNK;
-    while (c->stage_ev.size() < n_chunks) {
-        hipEvent_t e = nullptr;
-        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->stage_ev.push_back(e);
-    }
+    std::memset(c->h_flags, 0, n_blocks * sizeof(unsigned int));
+    std::atomic_thread_fence(std::memory_order_seq_cst);
     char* stage = static_cast<char*>(c->h_stage);
-    for (size_t k = 0; k < n_chunks; k++) {
-        const size_t off = k * CHUNK, len = std::min(CHUNK, bytes - off);
-        HIP_TRY(c, hipMemcpyAsync(stage + off, static_cast<const char*>(d_src) + off, len, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipEventRecord(c->stage_ev[k], c->stream));
-    }
-    const uint32_t n_thr = (uint32_t)std::min<size_t>(c->copy_threads, n_chunks);
+    hipLaunchKernelGGL(k_copy_out, dim3((unsigned)n_blocks), dim3(256), 0, c->stream, static_cast<const uint8_t*>(d_src), reinterpret_cast<uint8_t*>(stage),
+                       (unsigned long long)bytes, c->h_flags);
+    HIP_TRY(c, hipGetLastError());
+    // a mover takes runs of blocks: [k * RUN, (k + 1) * RUN) for k = t, t + n_thr, ...
+    const size_t RUN = 8;                                               // 256 KB per turn
+    const size_t n_runs = (n_blocks + RUN - 1) / RUN;
+    const uint32_t n_thr = (uint32_t)std::min<size_t>(c->copy_threads, n_runs);
     std::atomic<int> bad{0};
+    const bool dbg = std::getenv("RTGPU_DEBUG_COPY") != nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
     auto mover = [&](uint32_t t) {
         if (hipSetDevice(c->device) != hipSuccess) { bad = 1; return; }
-        for (size_t k = t; k < n_chunks; k += n_thr) {
-            if (hipEventSynchronize(c->stage_ev[k]) != hipSuccess) { bad = 1; return; }
-            const size_t off = k * CHUNK, len = std::min(CHUNK, bytes - off);
+        for (size_t r = t; r < n_runs && !bad; r += n_thr) {
+            const size_t b0 = r * RUN, b1 = std::min(n_blocks, b0 + RUN);
+            for (size_t bk = b0; bk < b1; bk++) {
+                unsigned long long spins = 0;
+                while (__atomic_load_n(&c->h_flags[bk], __ATOMIC_ACQUIRE) == 0u) {
+                    if (bad) return;
+                    if ((++spins & 0x3FFFull) == 0) {
+                        // no flag for a while: has the kernel ended (then its flags are up) or failed?
+                        const hipError_t q = hipStreamQuery(c->stream);
+                        if (q == hipSuccess) { if (__atomic_load_n(&c->h_flags[bk], __ATOMIC_ACQUIRE) == 0u) { bad = 1; return; } }
+                        else if (q != hipErrorNotReady) { bad = 1; return; }
+                        std::this_thread::yield();
+                    }
+                }
+            }
+            const size_t off = b0 * RT_COPY_BLOCK, len = std::min(bytes, b1 * (size_t)RT_COPY_BLOCK) - off;
             std::memcpy(static_cast<char*>(dst) + off, stage + off, len);
         }
     };
@@ -1471,7 +1489,9 @@ static int copy_frame_to_host(rt_ctx* c, void* dst, const void* d_src, size_t by
     for (uint32_t t = 1; t < n_thr; t++) th.emplace_back(mover, t);
     mover(0);
     for (auto& x : th) x.join();
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const hipError_t es = hipStreamSynchronize(c->stream);
+    if (dbg) std::fprintf(stderr, "  copy %zu MB: %.2f ms, threads %u\n", bytes >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count(), n_thr);
+    if (es != hipSuccess) return fail(c, RT_ERR_DEVICE, std::string("copying the frame to host memory: ") + hipGetErrorString(es));
     if (bad) return fail(c, RT_ERR_DEVICE, "copying the frame to host memory failed");
     return RT_OK;
 }
@@ -1912,6 +1932,11 @@ static int multi_render(rt_ctx* head, rt_multi& M, uint32_t n_frames, const rt_c
         return rt_render_shard_batch(m, (uint32_t)k, n, n_frames, cameras, plan.slots_per_shard, rgb, ids, &P.st);
     });
     if (rc != RT_OK) return rc;
+    const bool dbg = std::getenv("RTGPU_DEBUG_MULTI") != nullptr;
+    auto lap = [&](const char* what) {
+        if (dbg) std::fprintf(stderr, "  multi_render %-8s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
+    lap("rendered");
     if (n > 1 || M.api) {
         if ((rc = multi_gather(head, M, false, (size_t)plan.part_bytes_rgb)) != RT_OK) return rc;
         if (prim_id_out && (rc = multi_gather(head, M, true, (size_t)plan.part_bytes_ids)) != RT_OK) return rc;
@@ -1921,8 +1946,11 @@ static int multi_render(rt_ctx* head, rt_multi& M, uint32_t n_frames, const rt_c
         if ((rc = rt_detile_frames(head, M.gath_ids, n, n_frames, plan.slots_per_shard, 8, head->d_ids2)) != RT_OK) return rc;
         HIP_TRY(head, hipMemcpyAsync(prim_id_out, head->d_ids2, (size_t)head->vw * head->vh * 8 * n_frames, hipMemcpyDeviceToHost, head->stream));
     }
+    lap("detiled");
     touch.join();
+    lap("touched");
     if ((rc = copy_frame_to_host(head, rgb_out, M.frames, (size_t)plan.frame_bytes_rgb * n_frames)) != RT_OK) return rc;
+    lap("copied");
     HIP_TRY(head, hipGetLastError());
     if (stats_out) {
         // rays add up over the shards; times are the slowest member's (the members work side by side)
