@@ -1521,8 +1521,9 @@ int rt_render(rt_ctx* c, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* stat
     auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t px = (size_t)c->vw * (size_t)c->vh;
-    Prefault touch;
+    Prefault touch, touch_ids;
     touch.start(rgb_out, px * 3, c->copy_threads);
+    touch_ids.start(prim_id_out, px * 8, c->copy_threads);
     const int64_t slots = rt_shard_pixels(c->vw, c->vh, 0, 1);
     int rc;
     if ((rc = ensure_buf(c, &c->d_out, &c->d_out_cap, px * 3)) != RT_OK) return rc;
@@ -1537,7 +1538,8 @@ int rt_render(rt_ctx* c, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* stat
         ShardMap map = make_map(c->vw, c->vh, 0, 1, 1);
         hipLaunchKernelGGL(k_ids_rowmajor, dim3(((uint32_t)slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->dscene,
                            static_cast<const uint32_t*>(c->d_ids), static_cast<uint32_t*>(c->d_ids2), (uint32_t)slots, map);
-        HIP_TRY(c, hipMemcpyAsync(prim_id_out, c->d_ids2, px * 8, hipMemcpyDeviceToHost, c->stream));
+        touch_ids.join();      // (before any byte of the frame lands: the threads that touch the pages write to them)
+        if ((rc = copy_frame_to_host(c, prim_id_out, c->d_ids2, px * 8)) != RT_OK) return rc;
     }
     touch.join();
     if ((rc = copy_frame_to_host(c, rgb_out, c->d_out, px * 3)) != RT_OK) return rc;
@@ -1911,8 +1913,9 @@ static int multi_render(rt_ctx* head, rt_multi& M, uint32_t n_frames, const rt_c
     }
     HIP_TRY(head, hipSetDevice(head->device));
     int rc;
-    Prefault touch;
+    Prefault touch, touch_ids;
     touch.start(rgb_out, (size_t)plan.frame_bytes_rgb * n_frames, head->copy_threads);
+    touch_ids.start(prim_id_out, (size_t)head->vw * head->vh * 8 * n_frames, head->copy_threads);
     if ((rc = ensure_buf(head, &M.gath_rgb, &M.gath_rgb_cap, (size_t)plan.gathered_bytes_rgb)) != RT_OK) return rc;
     if (prim_id_out && (rc = ensure_buf(head, &M.gath_ids, &M.gath_ids_cap, (size_t)plan.gathered_bytes_ids)) != RT_OK) return rc;
     if ((rc = ensure_buf(head, &M.frames, &M.frames_cap, (size_t)plan.frame_bytes_rgb * n_frames)) != RT_OK) return rc;
@@ -1944,7 +1947,8 @@ static int multi_render(rt_ctx* head, rt_multi& M, uint32_t n_frames, const rt_c
     if ((rc = rt_detile_frames(head, M.gath_rgb, n, n_frames, plan.slots_per_shard, 3, M.frames)) != RT_OK) return rc;
     if (prim_id_out) {
         if ((rc = rt_detile_frames(head, M.gath_ids, n, n_frames, plan.slots_per_shard, 8, head->d_ids2)) != RT_OK) return rc;
-        HIP_TRY(head, hipMemcpyAsync(prim_id_out, head->d_ids2, (size_t)head->vw * head->vh * 8 * n_frames, hipMemcpyDeviceToHost, head->stream));
+        touch_ids.join();
+        if ((rc = copy_frame_to_host(head, prim_id_out, head->d_ids2, (size_t)head->vw * head->vh * 8 * n_frames)) != RT_OK) return rc;
     }
     lap("detiled");
     touch.join();
