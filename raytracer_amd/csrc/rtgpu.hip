@@ -32,7 +32,7 @@ namespace {
 
 thread_local std::string g_create_error = "";
 
-struct LevelAlloc { void* base = nullptr; size_t cap = 0; DLevel lv; };
+struct LevelAlloc { void* base = nullptr; size_t cap = 0; bool keys = false; DLevel lv; };
 
 // Per-level buffers and events of the shadow side of a level, which runs beside the trace of the next level
 struct LevelWork {
@@ -580,21 +580,22 @@ int upload_mesh(rt_ctx* c, const rt_mesh& m, rt_ctx::MeshCopy& mc, bool rebalanc
     return RT_OK;
 }
 
-size_t level_bytes(size_t cap) {
-    // 6+2+3+3 doubles, the key, 2 floats, 6 u32 per slot; each array padded to 256 B
+size_t level_bytes(size_t cap, bool keys) {
+    // 6+2+3+3 doubles, 2 floats, 6 u32 per slot, and in scenes with area lights the ray's key; each array padded to 256 B
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return 15 * pad(cap * 8) + 2 * pad(cap * 4) + 6 * pad(cap * 4);
+    return (keys ? 15 : 14) * pad(cap * 8) + 2 * pad(cap * 4) + 6 * pad(cap * 4);
 }
 
 int ensure_level(rt_ctx* c, size_t idx, size_t cap) {
     if (c->levels.size() <= idx) c->levels.resize(idx + 1);
     LevelAlloc& la = c->levels[idx];
-    if (la.cap >= cap && la.base) return RT_OK;
-    if (la.base) { (void)hipFree(la.base); c->work_bytes -= level_bytes(la.cap); la.base = nullptr; la.cap = 0; }
-    size_t bytes = level_bytes(cap);
+    const bool keys = c->has_area;     // (only the kernels of scenes with area lights read or write a level's keys)
+    if (la.cap >= cap && la.base && (la.keys || !keys)) return RT_OK;
+    if (la.base) { (void)hipFree(la.base); c->work_bytes -= level_bytes(la.cap, la.keys); la.base = nullptr; la.cap = 0; }
+    size_t bytes = level_bytes(cap, keys);
     if (hipMalloc(&la.base, bytes) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes for a wavefront level failed");
     c->work_bytes += bytes;
-    la.cap = cap;
+    la.cap = cap; la.keys = keys;
     char* p = static_cast<char*>(la.base);
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     auto takeD = [&]() { double* r = reinterpret_cast<double*>(p); p += pad(cap * 8); return r; };
@@ -608,7 +609,7 @@ int ensure_level(rt_ctx* c, size_t idx, size_t cap) {
     // the lit colour takes the normal's place: k_light, the normal's last reader, is the colour's writer (same thread, same slot)
     for (int k = 0; k < 3; k++) L.lit[k] = L.nrm[k];
     L.w_t = takeD(); L.w_r = takeD(); L.emis = takeD();
-    L.key = reinterpret_cast<unsigned long long*>(takeD());
+    L.key = keys ? reinterpret_cast<unsigned long long*>(takeD()) : nullptr;
     L.hit_u = takeF(); L.hit_v = takeF();
     L.hit_obj = takeU(); L.hit_prim = takeU(); L.child0 = takeU(); L.child1 = takeU(); L.base_flags = takeU(); L.result = takeU();
     return RT_OK;
