@@ -112,9 +112,19 @@ __device__ inline int prefix(const u64* keys, int n, int i, int j) {
     return __clzll((long long)(a ^ b));
 }
 
+// A subtree of the radix tree that covers at most this many triangles becomes one leaf (its triangles are neighbours on
+// the curve and lie in one run of the sorted order).  The reference's own builder stops splitting where a split does
+// not pay (acceleration.rs:356) and ends with two triangles per leaf on a regular mesh; one triangle per leaf means
+// twice the inner nodes for the walks to step through.
+#ifndef RT_LBVH_LEAF
+#define RT_LBVH_LEAF 2
+#endif
+
 // One inner node per thread (n - 1 of them over n sorted keys): the range of keys it covers and where it splits.
-// child[2 i], child[2 i + 1]: RT_LEAF_BIT | sorted position, or an inner node's index.  Node 0 is the root.
-__global__ __launch_bounds__(BB) void k_radix_tree(const u64* keys, int n, uint32_t* child, uint32_t* parent_inner, uint32_t* parent_leaf) {
+// child[2 i], child[2 i + 1]: RT_LEAF_BIT | first sorted position of a leaf, or an inner node's index.  Node 0 is the
+// root.  covers[i]: how many keys node i covers; a node that covers at most RT_LBVH_LEAF is referenced by its parent
+// as a leaf and is itself dead (never referenced, never emitted).  last[r]: position r ends a leaf.
+__global__ __launch_bounds__(BB) void k_radix_tree(const u64* keys, int n, uint32_t* child, uint32_t* parent_inner, uint32_t* covers, uint32_t* last) {
     const int i = blockIdx.x * BB + threadIdx.x;
     if (i >= n - 1) return;
     const int d = prefix(keys, n, i, i + 1) - prefix(keys, n, i, i - 1) < 0 ? -1 : 1;
@@ -133,17 +143,25 @@ __global__ __launch_bounds__(BB) void k_radix_tree(const u64* keys, int n, uint3
     } while (t > 1);
     const int gamma = i + s * d + (d < 0 ? -1 : 0);
     const int lo = i < j ? i : j, hi = i < j ? j : i;
-    if (lo == gamma) { child[2 * i] = RT_LEAF_BIT | (uint32_t)gamma; parent_leaf[gamma] = (uint32_t)i; }
-    else { child[2 * i] = (uint32_t)gamma; parent_inner[gamma] = (uint32_t)i; }
-    if (hi == gamma + 1) { child[2 * i + 1] = RT_LEAF_BIT | (uint32_t)(gamma + 1); parent_leaf[gamma + 1] = (uint32_t)i; }
-    else { child[2 * i + 1] = (uint32_t)(gamma + 1); parent_inner[gamma + 1] = (uint32_t)i; }
+    covers[i] = (uint32_t)(hi - lo + 1);
+    // the left child covers [lo, gamma], the right one [gamma + 1, hi]; an inner child's index is its split-side end
+    const bool dead = i != 0 && hi - lo + 1 <= RT_LBVH_LEAF;     // this node lies inside a leaf: its parent does not list it
+    if (gamma - lo + 1 <= RT_LBVH_LEAF) {
+        child[2 * i] = RT_LEAF_BIT | (uint32_t)lo;
+        if (!dead) for (int r = lo; r <= gamma; r++) last[r] = r == gamma ? 1u : 0u;
+    } else { child[2 * i] = (uint32_t)gamma; parent_inner[gamma] = (uint32_t)i; }
+    if (hi - gamma <= RT_LBVH_LEAF) {
+        child[2 * i + 1] = RT_LEAF_BIT | (uint32_t)(gamma + 1);
+        if (!dead) for (int r = gamma + 1; r <= hi; r++) last[r] = r == hi ? 1u : 0u;
+    } else { child[2 * i + 1] = (uint32_t)(gamma + 1); parent_inner[gamma + 1] = (uint32_t)i; }
     if (i == 0) parent_inner[0] = RT_NONE;
 }
 
-// inner nodes at even depth head a four-wide record
-__global__ __launch_bounds__(BB) void k_even_depth(const uint32_t* parent_inner, uint32_t n_inner, uint32_t* is4) {
+// live inner nodes at even depth head a four-wide record
+__global__ __launch_bounds__(BB) void k_even_depth(const uint32_t* parent_inner, const uint32_t* covers, uint32_t n_inner, uint32_t* is4) {
     const uint32_t i = blockIdx.x * BB + threadIdx.x;
     if (i >= n_inner) return;
+    if (i != 0 && covers[i] <= RT_LBVH_LEAF) { is4[i] = 0u; return; }     // inside a leaf
     uint32_t d = 0;
     for (uint32_t p = i; p != 0; p = parent_inner[p]) d++;
     is4[i] = (d & 1u) ? 0u : 1u;
@@ -197,7 +215,7 @@ __global__ __launch_bounds__(BB) void k_emit_wide(const uint32_t* child, const u
     atomicMax(stack_need, held + nk);
 }
 
-__global__ __launch_bounds__(BB) void k_emit_tris(const double* verts, const uint32_t* tri_pos, const uint32_t* order, uint32_t n, DTri* tris, int fresh) {
+__global__ __launch_bounds__(BB) void k_emit_tris(const double* verts, const uint32_t* tri_pos, const uint32_t* order, const uint32_t* last, uint32_t n, DTri* tris, int fresh) {
     const uint32_t r = blockIdx.x * BB + threadIdx.x;
     if (r >= n) return;
     const uint32_t t = fresh ? order[r] : tris[r].orig;
@@ -206,7 +224,7 @@ __global__ __launch_bounds__(BB) void k_emit_tris(const double* verts, const uin
     const double* v2 = verts + 3 * (size_t)tri_pos[3 * (size_t)t + 2];
     DTri& d = tris[r];
     for (int k = 0; k < 3; k++) { d.v0[k] = v0[k]; d.e1[k] = v1[k] - v0[k]; d.e2[k] = v2[k] - v0[k]; }   // mesh.rs:26-27
-    if (fresh) { d.orig = t; d.last = 1u; }
+    if (fresh) { d.orig = t; d.last = last ? last[r] : 1u; }
 }
 
 // f32 box of a node from its f64 bounds, rounded outward from the slab bounds the reference's test uses:
@@ -296,7 +314,7 @@ hipError_t bvh_refit_device(hipStream_t s, const double* d_verts, const uint32_t
         uint32_t* arrive = reinterpret_cast<uint32_t*>(tmp);
         double* own = reinterpret_cast<double*>(tmp + b_arrive);
         double* root = reinterpret_cast<double*>(tmp + b_arrive + b_own);
-        hipLaunchKernelGGL(k_emit_tris, GRID(n_records), dim3(BB), 0, s, d_verts, d_tri_pos, (const uint32_t*)nullptr, n_records, tris, 0);
+        hipLaunchKernelGGL(k_emit_tris, GRID(n_records), dim3(BB), 0, s, d_verts, d_tri_pos, (const uint32_t*)nullptr, (const uint32_t*)nullptr, n_records, tris, 0);
         if (n_inner) {
             TRY(hipMemsetAsync(arrive, 0, b_arrive, s));
             hipLaunchKernelGGL(k_refit, GRID(n_inner), dim3(BB), 0, s, d_verts, d_tri_pos, nodes, n_inner, tris, arrive, own, root);
@@ -326,7 +344,7 @@ hipError_t bvh_build_device(hipStream_t s, const double* d_verts, const uint32_t
         TRY((hipcub::DeviceScan::ExclusiveSum<const uint32_t*, uint32_t*>(nullptr, scan_bytes, nullptr, nullptr, (int)(ni ? ni : 1), s)));
         const size_t b_keys = align256((size_t)n * 8), b_idx = align256((size_t)n * 4), b_ni = align256((size_t)(ni + 1) * 4);
         const size_t b_cub = align256(std::max(sort_bytes, scan_bytes));
-        const size_t total = 2 * b_keys + 2 * b_idx + /* child */ 2 * b_ni + /* parent_inner, is4, idx4 */ 3 * b_ni + /* parent_leaf */ b_idx + b_cub + 512;
+        const size_t total = 2 * b_keys + 2 * b_idx + /* child */ 2 * b_ni + /* parent_inner, is4, idx4, covers */ 4 * b_ni + /* last */ b_idx + b_cub + 512;
         TRY(hipMalloc((void**)&tmp, total));
         char* p = tmp;
         auto take = [&](size_t b) { char* r = p; p += b; return r; };
@@ -334,7 +352,8 @@ hipError_t bvh_build_device(hipStream_t s, const double* d_verts, const uint32_t
         uint32_t* idx_in = (uint32_t*)take(b_idx); uint32_t* order = (uint32_t*)take(b_idx);
         uint32_t* child = (uint32_t*)take(2 * b_ni);
         uint32_t* parent_inner = (uint32_t*)take(b_ni); uint32_t* is4 = (uint32_t*)take(b_ni); uint32_t* idx4 = (uint32_t*)take(b_ni);
-        uint32_t* parent_leaf = (uint32_t*)take(b_idx);
+        uint32_t* last = (uint32_t*)take(b_idx);             // per sorted position: ends a leaf
+        uint32_t* covers = (uint32_t*)take(b_ni);
         void* cub = take(b_cub);
         unsigned* small = (unsigned*)take(512);      // [0..5] centroid bounds, [8] stack need
         const unsigned init[9] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -343,11 +362,10 @@ hipError_t bvh_build_device(hipStream_t s, const double* d_verts, const uint32_t
         hipLaunchKernelGGL(k_morton, GRID(n), dim3(BB), 0, s, d_verts, d_tri_pos, n, small, keys_in, idx_in);
         TRY((hipcub::DeviceRadixSort::SortPairs<u64, uint32_t>(cub, sort_bytes, keys_in, keys, idx_in, order, (int)n, 0, 63, s)));
         TRY(hipMalloc((void**)&tris, (size_t)n * sizeof(DTri)));
-        hipLaunchKernelGGL(k_emit_tris, GRID(n), dim3(BB), 0, s, d_verts, d_tri_pos, order, n, tris, 1);
         uint32_t n4 = 0, stack_need = 0;
         if (ni > 0) {
-            hipLaunchKernelGGL(k_radix_tree, GRID(ni), dim3(BB), 0, s, keys, (int)n, child, parent_inner, parent_leaf);
-            hipLaunchKernelGGL(k_even_depth, GRID(ni), dim3(BB), 0, s, parent_inner, ni, is4);
+            hipLaunchKernelGGL(k_radix_tree, GRID(ni), dim3(BB), 0, s, keys, (int)n, child, parent_inner, covers, last);
+            hipLaunchKernelGGL(k_even_depth, GRID(ni), dim3(BB), 0, s, parent_inner, covers, ni, is4);
             TRY((hipcub::DeviceScan::ExclusiveSum<const uint32_t*, uint32_t*>(cub, scan_bytes, is4, idx4, (int)ni, s)));
             uint32_t last[2] = {0, 0};
             TRY(hipMemcpyAsync(&last[0], idx4 + (ni - 1), 4, hipMemcpyDeviceToHost, s));
@@ -359,6 +377,8 @@ hipError_t bvh_build_device(hipStream_t s, const double* d_verts, const uint32_t
             TRY(hipGetLastError());
             TRY(hipMemcpyAsync(&stack_need, small + 8, 4, hipMemcpyDeviceToHost, s));
         }
+        // (a mesh of one triangle has no inner node and no leaf list: its one record ends its leaf)
+        hipLaunchKernelGGL(k_emit_tris, GRID(n), dim3(BB), 0, s, d_verts, d_tri_pos, order, ni > 0 ? last : (const uint32_t*)nullptr, n, tris, 1);
         out->root_ref = ni > 0 ? 0u : (RT_LEAF_BIT | 0u);
         out->ms_sort = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         TRY(bvh_refit_device(s, d_verts, d_tri_pos, n, nodes, n4, out->root_ref, tris, out->root_box));
