@@ -591,6 +591,10 @@ int ensure_level(rt_ctx* c, size_t idx, size_t cap) {
     LevelAlloc& la = c->levels[idx];
     const bool keys = c->has_area;     // (only the kernels of scenes with area lights read or write a level's keys)
     if (la.cap >= cap && la.base && (la.keys || !keys)) return RT_OK;
+    // A level that has to grow grows by an eighth more than asked: along a camera path the rays of a level drift up
+    // and down by a per cent or so from frame to frame, and a buffer sized exactly would be freed and allocated again
+    // (gigabytes, with the device idle meanwhile) for every frame that needs a few rays more than the last.
+    if (la.base && la.cap > 0 && cap > la.cap) cap += cap / 8;
     if (la.base) { (void)hipFree(la.base); c->work_bytes -= level_bytes(la.cap, la.keys); la.base = nullptr; la.cap = 0; }
     size_t bytes = level_bytes(cap, keys);
     if (hipMalloc(&la.base, bytes) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes for a wavefront level failed");
@@ -617,6 +621,7 @@ int ensure_level(rt_ctx* c, size_t idx, size_t cap) {
 
 int ensure_buf(rt_ctx* c, void** p, size_t* cap, size_t bytes) {
     if (*cap >= bytes && *p) return RT_OK;
+    if (*p && *cap > 0 && bytes > *cap) bytes += bytes / 8;     // (a buffer that grows: see ensure_level)
     if (*p) { (void)hipFree(*p); c->work_bytes -= *cap; *p = nullptr; *cap = 0; }
     if (hipMalloc(p, bytes) != hipSuccess) return fail(c, RT_ERR_NOMEM, "hipMalloc failed for an output buffer");
     *cap = bytes; c->work_bytes += bytes;
