@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <hip/hip_fp16.h>
 #include "dev_types.h"
 
 #define DEV __device__ __forceinline__
@@ -661,10 +662,11 @@ DEV bool tlas_object_near(const DScene& S, uint32_t oi, const Ray& ray, double& 
     if (kind == 0) return sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
     return box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
 }
-DEV bool tlas_leaf_near(const DScene& S, uint32_t what, const Ray& ray, double& near) {
-    const uint32_t payload = what & ~RT_TLAS_BOX;
-    if (!(what & RT_TLAS_BOX)) return sphere_near(gptr(S.spheres) + 4 * (size_t)payload, ray, near);
-    return box_near(gptr(S.boxes) + 6 * (size_t)payload, ray, near);
+// the object behind a leaf reference of a DTlasHalf record (its numbers by object index, DScene::tlas_geom)
+DEV bool tlas_leaf_near(const DScene& S, uint32_t ref, const Ray& ray, double& near) {
+    const RT_GLOBAL double* g = gptr(S.tlas_geom) + 6 * (size_t)(ref & ~(RT_TLAS_LEAF | RT_TLAS_BOX));
+    if (!(ref & RT_TLAS_BOX)) return sphere_near(g, ray, near);
+    return box_near(g, ray, near);
 }
 // cast_ray_once over the tree's objects: nearest by `near`, ties to the lower object index (scene.rs:57-82); `c` may
 // already hold the best of the objects outside the tree
@@ -724,21 +726,33 @@ __device__ bool tlas_any(const DScene& S, const Ray& ray, bool limited, double d
         if (W.ref[2] == RT_TLAS_NONE) (t2_) = INF;                                                                        \
         if (W.ref[3] == RT_TLAS_NONE) (t3_) = INF;                                                                        \
     } while (0)
-// compare-exchange of (distance, reference, leaf word) triples: afterwards ta <= tb
-#define RT_CSWAP3(ta, ra, wa, tb, rb, wb)                                     \
+// compare-exchange of (distance, reference) pairs: afterwards ta <= tb
+#define RT_CSWAP2(ta, ra, tb, rb)                                             \
     do {                                                                      \
         const bool sw_ = (tb) < (ta);                                         \
         const float tx_ = sw_ ? (tb) : (ta), ty_ = sw_ ? (ta) : (tb);         \
         const uint32_t rx_ = sw_ ? (rb) : (ra), ry_ = sw_ ? (ra) : (rb);      \
-        const uint32_t wx_ = sw_ ? (wb) : (wa), wy_ = sw_ ? (wa) : (wb);      \
-        (ta) = tx_; (tb) = ty_; (ra) = rx_; (rb) = ry_; (wa) = wx_; (wb) = wy_; \
+        (ta) = tx_; (tb) = ty_; (ra) = rx_; (rb) = ry_;                       \
     } while (0)
+// two half-precision floats of one word
+DEV void half_pair(uint32_t w, float& a, float& b) {
+    a = __half2float(__ushort_as_half((unsigned short)(w & 0xFFFFu)));
+    b = __half2float(__ushort_as_half((unsigned short)(w >> 16)));
+}
+// one 64-byte record (DTlasHalf) by four 16-byte loads, its boxes widened to f32 (exactly: every half is a float)
+typedef unsigned int __attribute__((ext_vector_type(4))) rt_w4;
+struct TlasRec { float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4]; uint32_t ref[4]; };
 #define RT_TQ_LOAD(cur_)                                                                      \
-    const RT_GLOBAL rt_d2* p_ = (const RT_GLOBAL rt_d2*)(quads + (cur_));                     \
-    union { rt_d2 q[8]; DTlasQuad w; } rec;                                                   \
-    rec.q[0] = p_[0]; rec.q[1] = p_[1]; rec.q[2] = p_[2]; rec.q[3] = p_[3];                   \
-    rec.q[4] = p_[4]; rec.q[5] = p_[5]; rec.q[6] = p_[6]; rec.q[7] = p_[7];                   \
-    const DTlasQuad& W = rec.w
+    const RT_GLOBAL rt_w4* p_ = (const RT_GLOBAL rt_w4*)(halves + (cur_));                    \
+    const rt_w4 q0_ = p_[0], q1_ = p_[1], q2_ = p_[2], q3_ = p_[3];                           \
+    TlasRec W;                                                                                \
+    half_pair(q0_.x, W.minx[0], W.minx[1]); half_pair(q0_.y, W.minx[2], W.minx[3]);           \
+    half_pair(q0_.z, W.miny[0], W.miny[1]); half_pair(q0_.w, W.miny[2], W.miny[3]);           \
+    half_pair(q1_.x, W.minz[0], W.minz[1]); half_pair(q1_.y, W.minz[2], W.minz[3]);           \
+    half_pair(q1_.z, W.maxx[0], W.maxx[1]); half_pair(q1_.w, W.maxx[2], W.maxx[3]);           \
+    half_pair(q2_.x, W.maxy[0], W.maxy[1]); half_pair(q2_.y, W.maxy[2], W.maxy[3]);           \
+    half_pair(q2_.z, W.maxz[0], W.maxz[1]); half_pair(q2_.w, W.maxz[2], W.maxz[3]);           \
+    W.ref[0] = q3_.x; W.ref[1] = q3_.y; W.ref[2] = q3_.z; W.ref[3] = q3_.w
 
 // tlas_closest for the kernels that own a per-lane stack (the lane-by-lane trace kernels): the four-wide records,
 // nearer children first, so that the nearest object is found early and the boxes behind it are never entered.  Same
@@ -746,7 +760,7 @@ __device__ bool tlas_any(const DScene& S, const Ray& ray, bool limited, double d
 // the lower index.
 __device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c, bool any) {
     const RT_GLOBAL DTlasNode* nodes = (const RT_GLOBAL DTlasNode*)S.tlas;
-    const RT_GLOBAL DTlasQuad* quads = (const RT_GLOBAL DTlasQuad*)S.tlas_quad;
+    const RT_GLOBAL DTlasHalf* halves = (const RT_GLOBAL DTlasHalf*)S.tlas_half;
     const bool cull = tlas_culls(ray);
     const float INF = __uint_as_float(0x7F800000u);
     int sp = 0;
@@ -754,11 +768,12 @@ __device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c
     float limit = any ? limit_up(c.t) : INF;
     float tn_root = -INF;
     if (cull && !(node_box(nodes[0].bmin, nodes[0].bmax, ray, tn_root) && !(tn_root > limit))) return any;
-    const PRay pr = pray_new_d(ray.o, ray.d, S.tlas_mesh.coord_max);
+    const PRay pr = pray_new_d(ray.o, ray.d, S.tlas_half_coord_max);
     // an object reached through a leaf reference: nearest by `near`, ties to the lower index
-    auto object = [&](uint32_t oi, uint32_t what) {
+    auto object = [&](uint32_t ref) {
+        const uint32_t oi = ref & ~(RT_TLAS_LEAF | RT_TLAS_BOX);
         double near;
-        if (tlas_leaf_near(S, what, ray, near) && (!any || near < c.t || (near == c.t && oi < c.obj))) {
+        if (tlas_leaf_near(S, ref, ray, near) && (!any || near < c.t || (near == c.t && oi < c.obj))) {
             c.obj = oi; c.rank = RT_NONE; c.t = near; c.t2 = 0.; c.u = 0.f; c.v = 0.f; any = true;
             limit = limit_up(near);
         }
@@ -769,13 +784,12 @@ __device__ bool tlas_closest_ordered(const DScene& S, const Ray& ray, Closest& c
         float t0, t1, t2, t3;
         RT_TQ_CHILDREN(t0, t1, t2, t3);
         uint32_t r0 = W.ref[0], r1 = W.ref[1], r2 = W.ref[2], r3 = W.ref[3];
-        uint32_t w0 = W.what[0], w1 = W.what[1], w2 = W.what[2], w3 = W.what[3];
-        RT_CSWAP3(t0, r0, w0, t1, r1, w1); RT_CSWAP3(t2, r2, w2, t3, r3, w3);
-        RT_CSWAP3(t0, r0, w0, t2, r2, w2); RT_CSWAP3(t1, r1, w1, t3, r3, w3);
-        RT_CSWAP3(t1, r1, w1, t2, r2, w2);
+        RT_CSWAP2(t0, r0, t1, r1); RT_CSWAP2(t2, r2, t3, r3);
+        RT_CSWAP2(t0, r0, t2, r2); RT_CSWAP2(t1, r1, t3, r3);
+        RT_CSWAP2(t1, r1, t2, r2);
         // leaves are tested on the spot, nearest first; what they find may close the children behind them
-#define RT_TQ_LEAF(t_, r_, w_) if ((t_) < INF && ((r_) & RT_TLAS_LEAF)) { if (!((t_) > limit)) object((r_) & ~RT_TLAS_LEAF, (w_)); (t_) = INF; }
-        RT_TQ_LEAF(t0, r0, w0) RT_TQ_LEAF(t1, r1, w1) RT_TQ_LEAF(t2, r2, w2) RT_TQ_LEAF(t3, r3, w3)
+#define RT_TQ_LEAF(t_, r_) if ((t_) < INF && ((r_) & RT_TLAS_LEAF)) { if (!((t_) > limit)) object(r_); (t_) = INF; }
+        RT_TQ_LEAF(t0, r0) RT_TQ_LEAF(t1, r1) RT_TQ_LEAF(t2, r2) RT_TQ_LEAF(t3, r3)
 #undef RT_TQ_LEAF
         // the inner children still open, farthest first: the nearest is walked next, the others wait on the stack
         if (sp + 3 > RT_MAX_STACK) return any;   // cannot happen: upload refuses a tree this deep
@@ -928,7 +942,7 @@ __device__ bool cast_any_seg(const DScene& S, const Ray& ray, bool limited, doub
 // tlas_any for a kernel that owns a per-lane stack: the four-wide records, nothing beyond `dist` entered.
 __device__ bool tlas_any_ordered(const DScene& S, const Ray& ray, bool limited, double dist) {
     const RT_GLOBAL DTlasNode* nodes = (const RT_GLOBAL DTlasNode*)S.tlas;
-    const RT_GLOBAL DTlasQuad* quads = (const RT_GLOBAL DTlasQuad*)S.tlas_quad;
+    const RT_GLOBAL DTlasHalf* halves = (const RT_GLOBAL DTlasHalf*)S.tlas_half;
     const bool cull = tlas_culls(ray);
     const float INF = __uint_as_float(0x7F800000u);
     int sp = 0;
@@ -936,7 +950,7 @@ __device__ bool tlas_any_ordered(const DScene& S, const Ray& ray, bool limited, 
     const float limit = limited ? limit_up(dist) : INF;
     float tn_root = -INF;
     if (cull && !(node_box(nodes[0].bmin, nodes[0].bmax, ray, tn_root) && !(tn_root > limit))) return false;
-    const PRay pr = pray_new_d(ray.o, ray.d, S.tlas_mesh.coord_max);
+    const PRay pr = pray_new_d(ray.o, ray.d, S.tlas_half_coord_max);
     uint32_t cur = 0;
     while (true) {
         RT_TQ_LOAD(cur);
@@ -945,7 +959,7 @@ __device__ bool tlas_any_ordered(const DScene& S, const Ray& ray, bool limited, 
         double near;
 #define RT_TQ_LEAF(k, t_)                                                                                   \
         if ((t_) < INF && (W.ref[k] & RT_TLAS_LEAF)) {                                                      \
-            if (tlas_leaf_near(S, W.what[k], ray, near) && (!limited || near <= dist)) return true;         \
+            if (tlas_leaf_near(S, W.ref[k], ray, near) && (!limited || near <= dist)) return true;          \
             (t_) = INF;                                                                                     \
         }
         RT_TQ_LEAF(0, t0) RT_TQ_LEAF(1, t1) RT_TQ_LEAF(2, t2) RT_TQ_LEAF(3, t3)

@@ -85,6 +85,19 @@ struct __attribute__((aligned(16))) DTlasQuad {
 #define RT_TLAS_NONE 0xFFFFFFFFu
 #define RT_TLAS_BOX 0x40000000u
 
+// The four-wide records once more, in 64 bytes, for the walks in which every lane fetches records of its own (the
+// lane-by-lane closest-hit and shadow casts): those walks are bound by the number of cache-line look-ups their loads
+// make -- 64 different lines per load instruction -- and not by arithmetic, so the boxes are kept as half-precision
+// floats, rounded outward (still conservative: a box only ever grows), and a record is four 16-byte loads instead
+// of eight.  A leaf child is RT_TLAS_LEAF | (RT_TLAS_BOX for a cube) | object index, and the object's own numbers
+// stand in DScene::tlas_geom at 6 doubles per object index (sphere: centre, radius; cube: position, half extent), so
+// that neither the object record nor a `what` word is fetched.
+struct __attribute__((aligned(16))) DTlasHalf {
+    uint16_t minx[4], miny[4], minz[4];
+    uint16_t maxx[4], maxy[4], maxz[4];
+    uint32_t ref[4];
+};
+
 struct DMaterial {
     uint32_t tex_kind;
     uint32_t tex_w, tex_h;
@@ -132,6 +145,10 @@ struct DScene {
     const DMesh* meshes;
     const DTlasNode* tlas;          // null when the scene has few analytic objects
     const DTlasQuad* tlas_quad;     // the same tree folded four-wide (record 0 = the root)
+    const DTlasHalf* tlas_half;     // ... and in 64-byte records with half-precision boxes, same numbering
+    const double* tlas_geom;        // [n_objects][6]: the tree's spheres and cubes by object index
+    float tlas_half_coord_max;      // the largest |coordinate| of any half-precision box
+    uint32_t _pad_tlas;
     DMesh tlas_mesh;                // the four-wide tree described like a mesh's (nodes, root box, coord_max, root_ref = 0): what the packet walks take
     const uint32_t* linear;         // indices of the objects the casts scan one by one (all that are not in the tree)
     uint32_t n_tlas, n_linear;

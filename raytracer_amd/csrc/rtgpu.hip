@@ -628,6 +628,43 @@ int ensure_buf(rt_ctx* c, void** p, size_t* cap, size_t bytes) {
     return RT_OK;
 }
 
+// ---- half-precision floats on the host (the 64-byte object-tree records): value of a bit pattern, and the nearest
+// patterns not above / not below a float (|x| below 65504)
+float half_value(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u;
+    float f;
+    if (e == 31u) { const uint32_t u = sign | 0x7F800000u | (m << 13); std::memcpy(&f, &u, 4); return f; }
+    if (e == 0u) { f = std::ldexp((float)m, -24); return sign ? -f : f; }
+    const uint32_t u = sign | ((e + 112u) << 23) | (m << 13);
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+uint16_t half_step(uint16_t h, bool up) {   // the next pattern above (up) or below the value of h
+    if (up) { if (h == 0x8000u) h = 0; return (h & 0x8000u) ? (uint16_t)(h - 1) : (uint16_t)(h + 1); }
+    if (h == 0) h = 0x8000u;
+    return (h & 0x8000u) ? (uint16_t)(h + 1) : (uint16_t)(h - 1);
+}
+uint16_t half_near(float x) {               // some pattern within one step of x (truncated mantissa)
+    uint32_t u; std::memcpy(&u, &x, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int e = (int)((u >> 23) & 255u) - 127 + 15;
+    if (e >= 31) return (uint16_t)(sign | 0x7BFFu);
+    if (e <= 0) return (uint16_t)sign;       // (tiny: +-0; the directed steps below take it from there)
+    return (uint16_t)(sign | ((uint32_t)e << 10) | ((u >> 13) & 1023u));
+}
+uint16_t half_down(float x) {               // the largest half <= x
+    uint16_t h = half_near(x);
+    while (half_value(h) > x) h = half_step(h, false);
+    while (half_value(half_step(h, true)) <= x) h = half_step(h, true);
+    return h;
+}
+uint16_t half_up(float x) {                 // the smallest half >= x
+    uint16_t h = half_near(x);
+    while (half_value(h) < x) h = half_step(h, true);
+    while (half_value(half_step(h, false)) >= x) h = half_step(h, false);
+    return h;
+}
+
 // ---- object tree (DTlasNode): median split of the objects' boxes on the widest axis of their centres, emitted in
 // depth-first order with skip links
 struct TlasItem { double lo[3], hi[3]; uint32_t object; };
@@ -1271,7 +1308,8 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
                 const rt_box& b = d->boxes[o.payload];
                 for (int k = 0; k < 3; k++) { it.lo[k] = b.pos[k] - std::fabs(b.half[k]); it.hi[k] = b.pos[k] + std::fabs(b.half[k]); }
             } else continue;
-            for (int k = 0; k < 3; k++) finite = finite && std::isfinite(it.lo[k]) && std::isfinite(it.hi[k]);
+            // (finite, and within the range of the half-precision boxes the lane-by-lane walks use)
+            for (int k = 0; k < 3; k++) finite = finite && std::isfinite(it.lo[k]) && std::isfinite(it.hi[k]) && std::fabs(it.lo[k]) < 6e4 && std::fabs(it.hi[k]) < 6e4;
             // an object with a NaN / infinite extent stays in the linear scan (and so does one whose index would not fit
             // beside the flag bit of a leaf record)
             // (... or beside the lane number of a queued (object, ray) pair)
@@ -1279,7 +1317,7 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
         }
         uint32_t tlas_min = 8;
         if (const char* e = std::getenv("RTGPU_TLAS_MIN")) tlas_min = (uint32_t)std::strtoul(e, nullptr, 10);
-        H.tlas = nullptr; H.tlas_quad = nullptr; H.n_tlas = 0;
+        H.tlas = nullptr; H.tlas_quad = nullptr; H.tlas_half = nullptr; H.tlas_geom = nullptr; H.tlas_half_coord_max = 0.f; H.n_tlas = 0;
         std::memset(&H.tlas_mesh, 0, sizeof(H.tlas_mesh));
         if (items.size() >= std::max<uint32_t>(tlas_min, 2)) {
             std::vector<DTlasNode> nodes;
@@ -1323,6 +1361,35 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
             // a step of the walk leaves at most three children waiting
             if (3 * (size_t)quad_depth > RT_MAX_STACK) return fail(c, RT_ERR_UNSUPPORTED, "object tree deeper than the traversal stack");
             if ((rc = upload(c, quads.data(), quads.size(), &H.tlas_quad)) != RT_OK) return rc;
+            {
+                // the same records in 64 bytes: half-precision boxes rounded outward, leaf references that carry the
+                // object's index and kind, and the objects' own numbers by object index
+                std::vector<DTlasHalf> halves(quads.size());
+                std::vector<double> geom((size_t)d->n_objects * 6, 0.);
+                float hmax = 0.f;
+                for (size_t q = 0; q < quads.size(); q++) {
+                    const DTlasQuad& Q = quads[q];
+                    DTlasHalf& Hf = halves[q];
+                    std::memset(&Hf, 0, sizeof(Hf));
+                    for (int k = 0; k < 4; k++) {
+                        Hf.ref[k] = Q.ref[k];
+                        if (Q.ref[k] == RT_TLAS_NONE) continue;
+                        Hf.minx[k] = half_down(Q.minx[k]); Hf.miny[k] = half_down(Q.miny[k]); Hf.minz[k] = half_down(Q.minz[k]);
+                        Hf.maxx[k] = half_up(Q.maxx[k]); Hf.maxy[k] = half_up(Q.maxy[k]); Hf.maxz[k] = half_up(Q.maxz[k]);
+                        for (uint16_t h : {Hf.minx[k], Hf.miny[k], Hf.minz[k], Hf.maxx[k], Hf.maxy[k], Hf.maxz[k]}) hmax = std::max(hmax, std::fabs(half_value(h)));
+                        if (Q.ref[k] & RT_TLAS_LEAF) {
+                            const uint32_t oi = Q.ref[k] & ~RT_TLAS_LEAF;
+                            const rt_object& o = d->objects[oi];
+                            Hf.ref[k] = RT_TLAS_LEAF | (o.kind == RT_OBJ_BOX ? RT_TLAS_BOX : 0u) | oi;
+                            if (o.kind == RT_OBJ_SPHERE) { for (int a = 0; a < 3; a++) geom[6 * (size_t)oi + a] = d->spheres[o.payload].c[a]; geom[6 * (size_t)oi + 3] = d->spheres[o.payload].r; }
+                            else for (int a = 0; a < 3; a++) { geom[6 * (size_t)oi + a] = d->boxes[o.payload].pos[a]; geom[6 * (size_t)oi + 3 + a] = d->boxes[o.payload].half[a]; }
+                        }
+                    }
+                }
+                if ((rc = upload(c, halves.data(), halves.size(), &H.tlas_half)) != RT_OK) return rc;
+                if ((rc = upload(c, geom.data(), geom.size(), &H.tlas_geom)) != RT_OK) return rc;
+                H.tlas_half_coord_max = hmax;
+            }
             // the packet walks take the tree as they take a mesh's: same records, the root's own box, the largest
             // |coordinate| of any box (it bounds the rounding error of their f32 slab arithmetic)
             std::memset(&H.tlas_mesh, 0, sizeof(H.tlas_mesh));
