@@ -2,6 +2,7 @@
 # usage: tools/pmc.sh <outdir-name> [prof_frame args...]   -- five PMC passes over tools/prof_frame.py
 # (run on the GPU box through gpurun; writes gpurun_out/<name>/*)
 R=$GRAFT_REPO_ROOT; N=$1; shift
+mkdir -p $(dirname $R/gpurun_out/$N)
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
 P2="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM"
