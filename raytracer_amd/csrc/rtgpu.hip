@@ -785,7 +785,8 @@ int ensure_level_counts(rt_ctx* c, size_t n) {
 //               bound of the next level's size); the host reads that back (one stream synchronisation per level)
 //               and gives the next level exactly that room;
 //   speculative (learned = the level sizes of an earlier frame of this context and shard) every launch of the frame
-//               is queued at once: level d is given room for a quarter more rays than it held last time, its launches
+//               is queued at once: level d is given room for a quarter more rays than it held last time (half more below
+//               level 1), its launches
 //               are sized for that room and read the real count from device memory.  If a level outgrows its room
 //               the frame is rendered again the measured way (`overflow`); a sequence's frames resemble each other,
 //               so that is rare.  No host round trip inside the frame: the launches of a small shard (a 1/8 frame is
@@ -827,7 +828,10 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
     if (learned) {
         for (size_t d = 1; d < learned->size() && d <= c->max_depth; d++) {
             const uint64_t worst = std::min<uint64_t>(2ull * room[d - 1], 0x7FFFFFFEull);
-            const uint64_t want = (*learned)[d] + (*learned)[d] / 4 + 4096;
+            // level 1 follows the picture closely from frame to frame; the deeper levels are small and jumpy (rays
+            // through a glass sphere that a few degrees of camera turn in or out of total reflection: +39 % from one
+            // set of ten frames to the next in scenes/refraction.sdl), and room for them costs little
+            const uint64_t want = d == 1 ? (*learned)[d] + (*learned)[d] / 4 + 4096 : (*learned)[d] + (*learned)[d] / 2 + 16384;
             room.push_back((uint32_t)std::min(worst, want));
         }
     }
@@ -1026,19 +1030,25 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
 // buffer as soon as it sees the error code.
 int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st,
                  uint32_t n_frames = 1, const DCamera* d_cams = nullptr, uint32_t frame_stride = 0) {
-    // the level sizes this context last saw for this shard of this frame size: the next frame is queued without
-    // waiting for its own (see render_frame_impl); RTGPU_SYNC_LEVELS=1 turns that off
-    const rt_ctx::LearnedKey key{shard, n_shards, c->vw, c->vh, c->max_depth, n_frames};
+    // the level sizes this context last saw for this shard of this frame size, per frame: the next frame (or set of
+    // frames: a set of n is given n times the room) is queued without waiting for its own (see render_frame_impl);
+    // RTGPU_SYNC_LEVELS=1 turns that off
+    const rt_ctx::LearnedKey key{shard, n_shards, c->vw, c->vh, c->max_depth, 0u};
     auto it = c->sync_levels ? c->learned.end() : c->learned.find(key);
     bool overflow = false;
-    std::vector<uint64_t> sizes;
-    int rc = render_frame_impl(c, shard, n_shards, row_major, n_frames, d_cams, frame_stride, d_rgb, d_ids, st, it != c->learned.end() ? &it->second : nullptr, overflow, sizes);
+    std::vector<uint64_t> sizes, scaled;
+    if (it != c->learned.end()) { scaled = it->second; for (auto& v : scaled) v *= n_frames; }
+    int rc = render_frame_impl(c, shard, n_shards, row_major, n_frames, d_cams, frame_stride, d_rgb, d_ids, st, it != c->learned.end() ? &scaled : nullptr, overflow, sizes);
     if (rc == RT_OK && overflow) {
         c->respeculated++;
         rc = render_frame_impl(c, shard, n_shards, row_major, n_frames, d_cams, frame_stride, d_rgb, d_ids, st, nullptr, overflow, sizes);
         if (rc == RT_OK && overflow) rc = fail(c, RT_ERR_DEVICE, "wavefront level overflow");
     }
-    if (rc == RT_OK) { c->learned[key] = sizes; if (st) st->respeculated = c->respeculated; }
+    if (rc == RT_OK) {
+        for (auto& v : sizes) v = (v + n_frames - 1) / n_frames;
+        c->learned[key] = sizes;
+        if (st) st->respeculated = c->respeculated;
+    }
     if (rc != RT_OK) {
         const std::string keep = c->err;
         if (c->stream) (void)hipStreamSynchronize(c->stream);
