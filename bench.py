@@ -17,9 +17,9 @@ renders the stretch of the path BEFORE the timed frames, as a running sequence w
 are queued with were learned from earlier frames, never from themselves (`frames_rendered_twice` counts the sets that
 outgrew them).  --frames-in-flight F sets of launches (default
 2) are in flight per GPU, each frame complete and delivered in order; F = 1 renders them strictly one after the other.
-A set of launches covers --batch B consecutive frames (rt_render_shard_batch): by default half of the K frames -- whole
-frames on one GPU, this rank's shard of them when the frame is sharded over N GPUs -- and at most ten whole frames' worth
-of rays, which keeps the launches large and the run down to one fill and one drain of the chip.  The line also carries the one-frame-at-a-time figure (`ms_per_frame_alone`) and, on one GPU, the time per
+A set of launches covers --batch B consecutive frames (rt_render_shard_batch): by default two 4K frames' worth of pixels
+on one GPU (whole frames fill the chip, and longer sets only hold more memory); this rank's shard of half of the K frames
+when the frame is sharded over N GPUs, at most ten whole frames' worth of rays, which keeps a rank's launches large.  The line also carries the one-frame-at-a-time figure (`ms_per_frame_alone`) and, on one GPU, the time per
 frame through rt_render, host pixels included (`ms_per_frame_end_to_end`).
 
 Roofline of the dominant kernel (the budget-free shadow packet kernel, k_shadow<false, false, false>): its launches are timed
@@ -163,14 +163,19 @@ def camera_path(base, f, still=False):
                   pitch=base.pitch, fov=base.fov)
 
 
-def default_batch(steps, world, small):
-    """Frames per set of launches when --batch is not given: half of the run's frames, at most ten whole frames' worth
-    of rays (10 x world shard frames) and at most RT_BATCH_MAX = 64; frames beyond 4K go one per set on one GPU and at
-    most `world` per set when sharded."""
+def default_batch(steps, world, small, pixels=3840 * 2160):
+    """Frames per set of launches when --batch is not given.  One GPU: as many frames as make up the pixels of two 4K
+    frames (2 at 4K, 8 at 1920x1080, 1 beyond 4K) -- larger sets hold more memory and are no faster (4K, 40 frames:
+    7.16 ms per frame and 7.3 GB of wavefront levels as sets of 2, 7.17 ms and 35.5 GB as sets of 10).  Sharded over N
+    GPUs a rank's launches are N times smaller, and only long sets restore their size: half of the run's frames, at most
+    ten whole frames' worth of rays (10 x world shard frames) and at most RT_BATCH_MAX = 64; frames beyond 4K at most
+    `world` per set."""
     half = (steps + 1) // 2
+    if world == 1:
+        return max(1, min(half, 64, (2 * 3840 * 2160) // max(1, pixels)))
     if small:
         return max(1, min(half, 10 * world, 64))
-    return 1 if world == 1 else max(1, min(half, world))
+    return max(1, min(half, world))
 
 
 def main():
@@ -187,7 +192,7 @@ def main():
     ap.add_argument("--lights", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--frames-in-flight", type=int, default=None)
-    ap.add_argument("--batch", type=int, default=None, help="frames per set of launches (default: half of the steps, at most ten whole frames' worth of rays)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per set of launches (default: two 4K frames' worth of pixels on one GPU; half of the steps, at most ten whole frames' worth of rays, when sharded)")
     ap.add_argument("--still", action="store_true", help="every frame through the scene's own camera (the same picture K times) instead of the camera path")
     args = ap.parse_args()
 
@@ -237,12 +242,10 @@ def main():
     # several consecutive frames per set of launches restore their size.
     small = vw * vh <= 3840 * 2160          # (an 8K frame's wavefront levels take tens of GB per frame in flight)
     if args.batch is None:
-        # The K frames as sets of launches of half of them each, two sets side by side: large sets fill the chip through
-        # their deep levels too, and every further set would add its own tail of small launches (one GPU, 20 frames:
-        # 7.09 ms per frame as 2 x 10, 7.18 as sets of 5, 7.24 as sets of 2 three at a time; a 1/8 shard of 20 frames is
-        # 20 ms of work all told).  At most ten whole frames' worth of rays per set (17 GB of wavefront levels at 4K);
-        # an 8K frame's levels take tens of GB each, so those go one frame per set.
-        args.batch = default_batch(args.steps, world, small)
+        # Sharded, the K frames go as sets of launches of half of them each, two sets side by side: large sets fill the
+        # chip through their deep levels too, and every further set would add its own tail of small launches (a 1/8 shard
+        # of 20 frames is 20 ms of work all told).  Whole frames on one GPU fill the chip by themselves: two per set.
+        args.batch = default_batch(args.steps, world, small, vw * vh)
     if args.frames_in_flight is None:
         args.frames_in_flight = 2
     depth, batch = max(1, args.frames_in_flight), max(1, args.batch)

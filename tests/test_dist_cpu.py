@@ -273,13 +273,13 @@ def test_gloo_frame_pipeline_keeps_frame_order(tmp_path):
 
 
 def test_bench_default_sets_of_launches():
-    """bench.py's choice of frames per set of launches: half of the run, within ten whole frames' worth of rays and the
-    library's limit; 8K frames one per set on one GPU"""
+    """bench.py's choice of frames per set of launches: on one GPU two 4K frames' worth of pixels; sharded, half of the
+    run, within ten whole frames' worth of rays and the library's limit"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    assert bench.default_batch(20, 1, True) == 10 and bench.default_batch(40, 1, True) == 10
+    assert bench.default_batch(20, 1, True) == 2 and bench.default_batch(40, 1, True, 1920 * 1080) == 8 and bench.default_batch(1, 1, True) == 1
     assert bench.default_batch(20, 8, True) == 10 and bench.default_batch(400, 8, True) == 64
     assert bench.default_batch(5, 2, True) == 3 and bench.default_batch(1, 4, True) == 1
-    assert bench.default_batch(20, 1, False) == 1 and bench.default_batch(20, 8, False) == 8
+    assert bench.default_batch(20, 1, False, 7680 * 4320) == 1 and bench.default_batch(20, 8, False) == 8
