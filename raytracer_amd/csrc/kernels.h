@@ -35,8 +35,19 @@ struct ShardMap {
     // a launch may cover this shard of several frames: level 0 holds them back to back, per_frame slots each; in the
     // compact output frame f starts at slot f * frame_stride (>= per_frame: the caller pads every shard to the largest)
     uint32_t per_frame, frame_stride;
+    // 1: this shard is one of n_shards PASSES over a frame whose compact output is the whole frame's (shard 0 of 1,
+    // whose rows are not rotated): a supertile's slots go where the whole frame keeps that supertile
+    uint32_t whole_frame_slots;
 };
-DEV size_t out_slot(const ShardMap& m, uint32_t i) { return (size_t)(i / m.per_frame) * m.frame_stride + i % m.per_frame; }
+DEV size_t out_slot(const ShardMap& m, uint32_t i) {
+    const uint32_t f = i / m.per_frame, j = i % m.per_frame;
+    if (!m.whole_frame_slots) return (size_t)f * m.frame_stride + j;
+    const uint32_t bits = 8u + 2u * m.super_shift;   // slots of a supertile
+    const uint64_t sid = (uint64_t)(j >> bits) * m.n_shards + m.shard;
+    const uint32_t sy = (uint32_t)(sid / m.supers_x);
+    const uint32_t sx = (uint32_t)((sid % m.supers_x + (uint64_t)sy * m.row_rot) % m.supers_x);
+    return (size_t)f * m.frame_stride + (((size_t)sy * m.supers_x + sx) << bits | (j & ((1u << bits) - 1u)));
+}
 
 DEV bool slot_pixel(const ShardMap& m, int32_t vw, int32_t vh, uint32_t slot, int32_t& x, int32_t& y) {
     const uint32_t sh = m.super_shift;

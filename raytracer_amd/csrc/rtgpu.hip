@@ -127,6 +127,7 @@ struct rt_ctx {
     uint32_t packet_depth = 0;                        // levels 0..packet_depth trace their rays as wave packets
     uint32_t defer_objects_below = 0;                 // scenes without meshes: levels below this one walk the object tree as deferred packets (the others lane by lane)
     bool defer_from_set = false;                      // RTGPU_DEFER_FROM given: no rule of thumb for level 0
+    uint32_t passes = 0;                              // RTGPU_PASSES: passes over a whole frame (0: by its size, see render_frame)
     uint64_t total_tris = 0;                          // triangles of all meshes of the uploaded scene
     bool defer_small = true;                          // ... also in launches small enough for the long-ray budgets
     uint32_t defer_from = 1;                          // levels from this one on walk meshes as packets with the triangle tests and the thin ends set aside (scenes without need_far meshes)
@@ -140,6 +141,9 @@ struct rt_ctx {
     // level sizes of the last frame rendered for (shard, n_shards, vw, vh, max_depth): what the next such frame is given room for
     typedef std::tuple<uint32_t, uint32_t, int32_t, int32_t, uint32_t, uint32_t> LearnedKey;
     std::map<LearnedKey, std::vector<uint64_t>> learned;
+    // rays of all levels of one whole frame, as last rendered, for (vw, vh, max_depth): what the choice of passes over a
+    // whole frame goes by (render_frame)
+    std::map<std::tuple<int32_t, int32_t, uint32_t>, uint64_t> whole_frame_rays;
     uint64_t scene_shape = 0;                         // counts of the last uploaded scene (objects, lights, meshes, triangles): see scene_upload
     bool sync_levels = false;                         // RTGPU_SYNC_LEVELS=1: always read each level's size back before the next
     uint64_t respeculated = 0;                        // frames rendered twice because a level outgrew its room
@@ -729,6 +733,7 @@ ShardMap make_map(int32_t vw, int32_t vh, uint32_t shard, uint32_t n_shards, uin
     m.n_supers = m.supers_x * (uint32_t)((vh + side - 1) / side);
     m.row_rot = shard_row_rotation(m.supers_x, n_shards);
     m.row_major_out = row_major;
+    m.whole_frame_slots = 0;
     const int64_t px = rt_shard_pixels(vw, vh, shard, n_shards);
     m.per_frame = m.frame_stride = px > 0 ? (uint32_t)px : 1u;
     return m;
@@ -796,9 +801,11 @@ int ensure_level_counts(rt_ctx* c, size_t n) {
 // set of launches: level 0 holds the frames' primary rays one frame after the other, and nothing below level 0
 // knows of frames.  Eight 1/8-frame shards make launches as large as a whole frame's, and a GPU that owns one shard
 // of a sequence works as efficiently as a GPU that owns whole frames.
+// pass_of_whole: the shard is one of n_shards passes over a whole frame (render_frame): compact output goes to the whole
+// frame's slots, and frame_stride is the whole frame's.
 int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint32_t n_frames, const DCamera* d_cams, uint32_t frame_stride,
                       uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st,
-                      const std::vector<uint64_t>* learned, bool& overflow, std::vector<uint64_t>& level_sizes) {
+                      const std::vector<uint64_t>* learned, bool& overflow, std::vector<uint64_t>& level_sizes, bool pass_of_whole) {
     overflow = false;
     if (!c->have_scene) return fail(c, RT_ERR_INVALID, "no scene uploaded");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -809,6 +816,10 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
     const uint32_t n0 = per_frame * n_frames;
     ShardMap map = make_map(c->vw, c->vh, shard, n_shards, row_major);
     if (n_frames > 1) map.frame_stride = frame_stride;
+    if (pass_of_whole) {
+        map.whole_frame_slots = 1;
+        if (n_frames == 1) map.frame_stride = (uint32_t)rt_shard_pixels(c->vw, c->vh, 0, 1);
+    }
     rt_stats stats; std::memset(&stats, 0, sizeof(stats));
     stats.rays_primary = valid_pixels(map, c->vw, c->vh) * n_frames;
     stats.rays_per_level[0] = stats.rays_primary;
@@ -1028,8 +1039,8 @@ int render_frame_impl(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row
 // Every error exit of a frame passes through here: kernels of earlier levels may still be writing the level buffers,
 // the occlusion bytes or the caller's output buffer on the main and side streams, and the caller may free that
 // buffer as soon as it sees the error code.
-int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st,
-                 uint32_t n_frames = 1, const DCamera* d_cams = nullptr, uint32_t frame_stride = 0) {
+int render_shard_once(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st,
+                      uint32_t n_frames, const DCamera* d_cams, uint32_t frame_stride, bool pass_of_whole) {
     // the level sizes this context last saw for this shard of this frame size, per frame: the next frame (or set of
     // frames: a set of n is given n times the room) is queued without waiting for its own (see render_frame_impl);
     // RTGPU_SYNC_LEVELS=1 turns that off
@@ -1038,10 +1049,10 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
     bool overflow = false;
     std::vector<uint64_t> sizes, scaled;
     if (it != c->learned.end()) { scaled = it->second; for (auto& v : scaled) v *= n_frames; }
-    int rc = render_frame_impl(c, shard, n_shards, row_major, n_frames, d_cams, frame_stride, d_rgb, d_ids, st, it != c->learned.end() ? &scaled : nullptr, overflow, sizes);
+    int rc = render_frame_impl(c, shard, n_shards, row_major, n_frames, d_cams, frame_stride, d_rgb, d_ids, st, it != c->learned.end() ? &scaled : nullptr, overflow, sizes, pass_of_whole);
     if (rc == RT_OK && overflow) {
         c->respeculated++;
-        rc = render_frame_impl(c, shard, n_shards, row_major, n_frames, d_cams, frame_stride, d_rgb, d_ids, st, nullptr, overflow, sizes);
+        rc = render_frame_impl(c, shard, n_shards, row_major, n_frames, d_cams, frame_stride, d_rgb, d_ids, st, nullptr, overflow, sizes, pass_of_whole);
         if (rc == RT_OK && overflow) rc = fail(c, RT_ERR_DEVICE, "wavefront level overflow");
     }
     if (rc == RT_OK) {
@@ -1057,6 +1068,84 @@ int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_majo
         c->err = keep;
     }
     return rc;
+}
+
+// Passes over a whole frame.  The wavefront levels of a frame take memory in proportion to its rays (8K,
+// scenes/huge_grid.sdl: 377 M rays in five levels, 115 GB), and a chip is full long before that: a whole frame (or set
+// of whole frames) whose levels would take more than RT_PASS_BUDGET is rendered as P shards one after the other through
+// the same level buffers, every pass writing its pixels where the whole frame's launches would have written them.
+// The levels' size is known from the last such frame of the scene (about RT_PASS_BYTES_PER_RAY with the per-level work
+// lists and the room levels are given); before there is one, frames of more than two 4K frames' pixels go in passes of
+// one 4K frame's.  Passes cost a light frame time (8K terrain, 2.4 rays per pixel: 6.9 ms whole, 7.5 in two passes,
+// 8.1 in four) and a heavy one nothing (huge_grid: 119.6 / 119.7 / 120.4 ms).
+// RTGPU_PASSES=P in the environment fixes P (1: never).
+#define RT_PASS_PIXELS (3840ull * 2160ull)
+#define RT_PASS_BUDGET (32ull << 30)
+#define RT_PASS_BYTES_PER_RAY 290ull
+uint32_t passes_for(const rt_ctx* c, uint32_t n_frames) {
+    const uint64_t supers = (uint64_t)rt_shard_pixels(c->vw, c->vh, 0, 1) >> (8u + 2u * super_shift());
+    uint64_t p = c->passes;
+    if (p == 0) {
+        const auto it = c->whole_frame_rays.find(std::make_tuple(c->vw, c->vh, c->max_depth));
+        if (it != c->whole_frame_rays.end()) {
+            const uint64_t bytes = it->second * n_frames * RT_PASS_BYTES_PER_RAY;
+            p = (bytes + RT_PASS_BUDGET - 1) / RT_PASS_BUDGET;
+        } else {
+            const uint64_t px = (uint64_t)c->vw * (uint64_t)c->vh * n_frames;
+            p = px > 2 * RT_PASS_PIXELS ? (px + RT_PASS_PIXELS - 1) / RT_PASS_PIXELS : 1;
+        }
+    }
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({p, supers, 64}));
+}
+
+int render_frame(rt_ctx* c, uint32_t shard, uint32_t n_shards, uint32_t row_major, uint8_t* d_rgb, uint32_t* d_ids, rt_stats* st,
+                 uint32_t n_frames = 1, const DCamera* d_cams = nullptr, uint32_t frame_stride = 0) {
+    const uint32_t passes = n_shards == 1 && c->have_scene ? passes_for(c, n_frames) : 1;
+    auto note_rays = [&](const rt_stats& s) {
+        uint64_t rays = 0;
+        for (int d = 0; d < 8; d++) rays += s.rays_per_level[d];
+        c->whole_frame_rays[std::make_tuple(c->vw, c->vh, c->max_depth)] = (rays + n_frames - 1) / n_frames;
+    };
+    if (passes == 1) {
+        rt_stats one;
+        const int rc = render_shard_once(c, shard, n_shards, row_major, d_rgb, d_ids, &one, n_frames, d_cams, frame_stride, false);
+        if (rc == RT_OK && n_shards == 1) note_rays(one);
+        if (rc == RT_OK && st) *st = one;
+        return rc;
+    }
+    rt_stats sum; std::memset(&sum, 0, sizeof(sum));
+    for (uint32_t p = 0; p < passes; p++) {
+        rt_stats one;
+        const int rc = render_shard_once(c, p, passes, row_major, d_rgb, d_ids, &one, n_frames, d_cams, frame_stride, true);
+        if (rc != RT_OK) return rc;
+        // the passes run one after the other: rays and times add up
+        sum.rays_primary += one.rays_primary; sum.rays_reflect += one.rays_reflect; sum.rays_transmit += one.rays_transmit; sum.rays_shadow += one.rays_shadow;
+        for (int d = 0; d < 8; d++) sum.rays_per_level[d] += one.rays_per_level[d];
+        sum.ms_render += one.ms_render; sum.ms_trace += one.ms_trace; sum.ms_shadow += one.ms_shadow; sum.ms_shade += one.ms_shade;
+        sum.ms_resolve += one.ms_resolve; sum.ms_shadow_main += one.ms_shadow_main;
+        sum.nodes_visited += one.nodes_visited; sum.tris_tested += one.tris_tested; sum.wave_nodes += one.wave_nodes; sum.wave_tris += one.wave_tris;
+        sum.launches_trace += one.launches_trace; sum.launches_shadow += one.launches_shadow; sum.launches_shade += one.launches_shade;
+        sum.launches_shadow_main += one.launches_shadow_main;
+        sum.long_trace += one.long_trace; sum.long_shadow += one.long_shadow; sum.bytes_fetched += one.bytes_fetched; sum.bytes_fetched_main += one.bytes_fetched_main;
+        sum.max_lane_steps = std::max(sum.max_lane_steps, one.max_lane_steps); sum.max_wave_steps = std::max(sum.max_wave_steps, one.max_wave_steps);
+        sum.speculative = p == 0 ? one.speculative : (sum.speculative && one.speculative ? 1u : 0u);
+        sum.ms_upload = one.ms_upload; sum.device_bytes = one.device_bytes; sum.respeculated = one.respeculated;
+    }
+    note_rays(sum);
+    {
+        // the whole frame's level sizes are the sums of the passes': should the next frame go in one pass (a light frame,
+        // once that is known), it is queued with them like any other
+        std::vector<uint64_t> whole;
+        for (uint32_t p = 0; p < passes; p++) {
+            const auto it = c->learned.find(rt_ctx::LearnedKey{p, passes, c->vw, c->vh, c->max_depth, 0u});
+            if (it == c->learned.end()) continue;
+            if (whole.size() < it->second.size()) whole.resize(it->second.size(), 0);
+            for (size_t d = 0; d < it->second.size(); d++) whole[d] += it->second[d];
+        }
+        if (!whole.empty()) c->learned[rt_ctx::LearnedKey{0u, 1u, c->vw, c->vh, c->max_depth, 0u}] = whole;
+    }
+    if (st) *st = sum;
+    return RT_OK;
 }
 
 }  // namespace
@@ -1099,6 +1188,7 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         if (const char* b = std::getenv("RTGPU_DEFER_SMALL")) c->defer_small = b[0] != '0';
         if (const char* b = std::getenv("RTGPU_DEFER_OBJECTS_BELOW")) c->defer_objects_below = (uint32_t)std::strtoul(b, nullptr, 10);
         if (const char* b = std::getenv("RTGPU_BUDGET_BELOW")) c->long_below = (uint32_t)std::strtoul(b, nullptr, 10);
+        if (const char* b = std::getenv("RTGPU_PASSES")) c->passes = (uint32_t)std::strtoul(b, nullptr, 10);
     }
     for (auto& ev : c->ev) ev = nullptr;
     auto bail = [&](const char* what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); rt_ctx_destroy(c); return RT_ERR_DEVICE; };
@@ -1482,7 +1572,7 @@ static int scene_upload(rt_ctx* c, const rt_scene_desc* d) {
         bool same = true;
         for (uint32_t i = 0; i < d->n_meshes; i++) if (d->meshes[i].unchanged == 0) same = false;
         const uint64_t shape = ((uint64_t)d->n_objects * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)H.n_lights << 40) ^ ((uint64_t)d->n_meshes << 20) ^ (c->total_tris << 1) ^ 1ull;
-        if (!same || shape != c->scene_shape) c->learned.clear();
+        if (!same || shape != c->scene_shape) { c->learned.clear(); c->whole_frame_rays.clear(); }
         c->scene_shape = shape;
     }
     c->have_scene = true;

@@ -708,6 +708,50 @@ def test_batched_shards_of_a_camera_path_equal_the_frames_rendered_one_by_one():
         assert e.value.code == N.RT_ERR_INVALID
 
 
+@pytest.mark.parametrize("passes", [2, 3, 5, 64])
+def test_a_whole_frame_rendered_in_passes_is_the_same_frame(passes, monkeypatch):
+    """A large frame is rendered as several passes through the same level buffers (RTGPU_PASSES forces it on a small
+    one): pixels, ids and ray counts of rt_render, the compact whole-frame buffer of rt_render_shard(0, 1), and a set of
+    frames along a camera path (rt_render_frames, rt_render_shard_batch) equal those of one pass and the oracle's."""
+    import torch
+    vw, vh = 328, 200    # 6 x 4 supertiles of 64 x 64 pixels, the last column and row cut by the frame's edge
+    cams = [ra.Camera(vw=vw, vh=vh, origin=(0.3 * f, 2.0 + 0.2 * f, 6.0), yaw=0.05 * f, pitch=-0.35 + 0.03 * f, fov=60. - 4 * f) for f in range(3)]
+    for s in (scenes.small_mixed_scene(vw, vh, cells=10), scenes.huge_grid_scene(vw, vh, 4)):
+        monkeypatch.setenv("RTGPU_PASSES", "1")
+        slots = rd.max_shard_slots(vw, vh, 1)
+        with ra.Context(0) as ctx:
+            ctx.upload(s)
+            for rep in range(2):
+                want_rgb, want_ids, want_st = ctx.render(ids=True)
+            want_compact = torch.zeros(slots * 3, dtype=torch.uint8, device="cuda")
+            ctx.render_shard(0, 1, want_compact.data_ptr())
+            want_frames, _, want_fst = ctx.render_frames(cams)
+            torch.cuda.synchronize()
+            one_pass_bytes = want_st.device_bytes
+        o_rgb, o_ids, o_st, _ = oracle.render(s, 0)
+        assert np.array_equal(want_rgb, o_rgb) and np.array_equal(want_ids, o_ids)
+        monkeypatch.setenv("RTGPU_PASSES", str(passes))
+        with ra.Context(0) as ctx:
+            ctx.upload(s)
+            for rep in range(2):    # second time: every pass queued with the sizes its first run learned
+                rgb, ids, st = ctx.render(ids=True)
+                assert np.array_equal(rgb, want_rgb) and np.array_equal(ids, want_ids)
+                assert ray_counts(st) == ray_counts(want_st) == ray_counts(o_st)
+                assert list(st.rays_per_level) == list(want_st.rays_per_level)
+            assert st.speculative == 1
+            assert st.device_bytes < one_pass_bytes, (st.device_bytes, one_pass_bytes)
+            compact = torch.full((slots * 3,), 7, dtype=torch.uint8, device="cuda")
+            ctx.render_shard(0, 1, compact.data_ptr())
+            frames, _, fst = ctx.render_frames(cams)
+            torch.cuda.synchronize()
+            # (slots of tiles outside the frame are never written: compare what a de-tile reads)
+            a = torch.zeros(vh * vw * 3, dtype=torch.uint8, device="cuda"); b = torch.zeros_like(a)
+            ctx.detile(compact.data_ptr(), 1, slots, 3, a.data_ptr())
+            ctx.detile(want_compact.data_ptr(), 1, slots, 3, b.data_ptr())
+            assert torch.equal(a, b) and np.array_equal(a.cpu().numpy().reshape(vh, vw, 3), want_rgb)
+            assert np.array_equal(frames, want_frames) and fst.rays == want_fst.rays
+
+
 def test_device_frames_equal_the_reference_authors_own_renders(gpu_ctx):
     """The device path against output the reference itself holds (no oracle in between): the three icosphere images
     of its README (scenes/icosahedron.sdl, orders 0, 2, 5) byte for byte, and the 1920x1080 cube scene of
