@@ -175,7 +175,9 @@ typedef struct rt_stats {
     uint64_t rays_primary, rays_reflect, rays_transmit, rays_shadow;
     uint64_t rays_per_level[8];   /* trace_ray invocations per depth        */
     double   ms_upload;           /* last rt_scene_upload                   */
-    double   ms_render;           /* first to last kernel of the last frame (HIP events on the main stream) */
+    double   ms_render;           /* first to last kernel of the last frame (HIP events on the main stream); a frame
+                                   * rendered in several passes (large frames, see rt_render): the passes' sum, like the
+                                   * other times and the counts below */
     double   ms_total;            /* render + copy-out wall time            */
     /* Per phase, the launches' own durations summed over depths (HIP events on the stream each phase runs on):
      * closest-hit casts; shadow casts; spawn + lighting; the final fold.  The phases of a frame overlap (the shadow
@@ -270,7 +272,12 @@ int rt_set_area_seed(rt_ctx* ctx, uint64_t seed);
  *   prim_id_out nullable; 2 u32 per pixel = (object index in scene order,
  *               triangle index in the mesh's own order) of the primary hit;
  *               RT_ID_NONE = miss / not a mesh
- *   stats_out   nullable */
+ *   stats_out   nullable
+ * The device memory a frame's rays take goes with their number (about 290
+ * bytes a ray).  A frame, or set of frames, that would take more than 32 GB is
+ * rendered in several passes over interleaved parts of the image through the
+ * same buffers, each pass writing its pixels in place: same frame, 1 % more
+ * time where it applies (RTGPU_PASSES in the environment fixes the number). */
 int rt_render(rt_ctx* ctx, uint8_t* rgb_out, uint32_t* prim_id_out, rt_stats* stats_out);
 
 /* Image-space sharding for one-process-per-GPU runs (pixels are independent,
