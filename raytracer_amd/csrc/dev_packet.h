@@ -199,7 +199,7 @@ __shared__ uint32_t rt_qpair[RT_PWAVES * RT_QCAP];
 #define RT_QFLUSH_OBJ RT_QFLUSH   /* the same for the closest-hit walk of an object tree */
 #endif
 #ifndef RT_NCAP
-#define RT_NCAP 224
+#define RT_NCAP 236   /* (with the other arrays of a shadow workgroup, the counting variants' included: 23,024 bytes of the 23,040 that 18 LDS granules hold) */
 #endif
 #ifndef RT_NFLUSH
 #define RT_NFLUSH 48    /* node pairs waiting at which the packet walk stops for a round of node tests */
